@@ -1,0 +1,63 @@
+"""Generate tests/golden/*.npz from the CPU oracle (TEST INFRASTRUCTURE; see oracle/cbfssm_oracle.py header).
+
+PARITY UNPINNED: the vectors are outputs of this repo's own float64 restatement of the reference, not of the
+reference itself (TensorFlow 1.8 is not installable here; the reference holds no fixtures).  Run from the repo root:
+
+    python oracle/make_golden.py
+"""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'cbf-ssm_amd')]
+
+from cbfssm import synthetic as syn          # noqa: E402
+from oracle import cbfssm_oracle as orc      # noqa: E402
+from oracle import cbfssm_torch_ref as tref  # noqa: E402
+
+CASES = {
+    # generic small case, every dimension distinct, both loss factors active, windows shorter than T
+    'tiny': syn.tiny(),
+    # shrunken Sarcos: real dims (7/7/14, D=21), k_factor 50, small M/T/B/S
+    'mini_sarcos': syn.Workload('mini_sarcos', dim_u=7, dim_y=7, dim_x=14, M=24, T=40, B=3, S=6, recog_len=16,
+                                k_factor=50., loss_factors=(6., 0.3), var_y=0.05 ** 2),
+    # shrunken small-scale (Actuator-like 1/1/4, D=5), M not a multiple of 16, ragged T vs 2R
+    'mini_smallscale': syn.Workload('mini_smallscale', dim_u=1, dim_y=1, dim_x=4, M=20, T=37, B=5, S=7,
+                                    recog_len=16, k_factor=100., loss_factors=(0.5, 0.1), gp_len=2.),
+}
+
+
+def main():
+    out_dir = os.path.join(ROOT, 'tests', 'golden')
+    os.makedirs(out_dir, exist_ok=True)
+    for name, w in CASES.items():
+        cfg = w.model_config()
+        p = syn.perturb_params(syn.make_params(w, seed=1))
+        u, y = syn.make_inputs(w, seed=0)
+        noise = syn.make_noise(w, seed=2)
+        blob = {'workload_' + k: np.asarray(v) for k, v in syn.workload_dict(w).items() if k != 'name'}
+        blob.update({'param_' + k: v for k, v in p.items()})
+        blob.update({'u': u, 'y': y})
+        blob.update({'noise_' + k: v for k, v in noise.items()})
+        for cond in (True, False):
+            tag = 'c1_' if cond else 'c0_'
+            trace = {}
+            res = orc.elbo_step(cfg, p, u, y, noise, cond, trace)
+            for k in ('loss', 'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b', 'pred_mean', 'pred_var',
+                      'x_final', 'y_tilde'):
+                blob[tag + k] = np.asarray(res[k])
+            if cond:
+                # one GP call of each pass, for the stand-alone gp_predict kernel
+                blob['f_fmean_t0'] = trace['f_fmean'][0]
+                blob['f_fvar_t0'] = trace['f_fvar'][0]
+            scal, grads = tref.loss_and_grads(cfg, p, u, y, noise, cond)
+            assert abs(scal['loss'] - res['loss']) <= 1e-9 * abs(res['loss'])
+            blob.update({tag + 'grad_' + k: g for k, g in grads.items()})
+        path = os.path.join(out_dir, name + '.npz')
+        np.savez_compressed(path, **blob)
+        print(name, os.path.getsize(path) // 1024, 'KiB', 'loss', blob['c1_loss'])
+
+
+if __name__ == '__main__':
+    main()
