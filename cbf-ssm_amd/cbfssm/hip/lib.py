@@ -1,0 +1,91 @@
+"""ctypes binding of libcbfssm_hip.so (C ABI: include/cbfssm_hip.h).
+
+The library is the product: if it cannot be loaded every entry point raises -- there is no CPU or eager-PyTorch
+fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libcbfssm_hip.so'))
+
+SCAL_SIGMA2, SCAL_LOGDET, SCAL_KLZ, SCAL_INFO, SCAL_COUNT = 0, 1, 2, 3, 8
+JITTER = 1e-8   # cbfssm/model/gp_tf.py:57
+
+# every symbol include/cbfssm_hip.h declares (tests check the shared object exports all of them)
+SYMBOLS = (
+    'cbfssm_last_error', 'cbfssm_version', 'cbfssm_gp_pack_layout', 'cbfssm_kmm_chol_f64', 'cbfssm_gp_prepare_f64',
+    'cbfssm_gp_predict_f64', 'cbfssm_backward_pass_partials', 'cbfssm_backward_pass_f64',
+    'cbfssm_forward_pass_partials', 'cbfssm_forward_pass_f64', 'cbfssm_loglik_moments_f64',
+    'cbfssm_elbo_combine_f64',
+)
+
+
+class PackLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ('total', 'Bp', 'Zp', 'cz', 'muA', 's2A', 'invl', 'scal', 'Kmm', 'L', 'Kinv',
+                                          'Linvt', 'Zs')] + \
+               [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS')]
+
+
+class Problem(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('B', 'S', 'T', 'dim_x', 'dim_u', 'dim_y', 'M', 'recog_len', 'condition',
+                                          'pad_')] + [('k_factor', C.c_double)]
+
+
+class CbfssmHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it is missing: build it with `python __graft_entry__.py`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CbfssmHipError('HIP extension not built: %s is missing (run __graft_entry__.build() / make -C '
+                             'cbf-ssm_amd/csrc). There is no fallback path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    lib.cbfssm_last_error.restype = C.c_char_p
+    lib.cbfssm_last_error.argtypes = []
+    lib.cbfssm_version.restype = ip
+    lib.cbfssm_gp_pack_layout.argtypes = [ip, ip, ip, C.POINTER(PackLayout)]
+    lib.cbfssm_kmm_chol_f64.argtypes = [ip, ip, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
+    lib.cbfssm_gp_prepare_f64.argtypes = [C.POINTER(PackLayout), vp, vp, vp, vp, vp, dbl, vp, vp]
+    lib.cbfssm_gp_predict_f64.argtypes = [C.POINTER(PackLayout), vp, vp, i64, vp, vp, vp]
+    lib.cbfssm_backward_pass_partials.restype = i64
+    lib.cbfssm_backward_pass_partials.argtypes = [C.POINTER(Problem)]
+    lib.cbfssm_backward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10
+    lib.cbfssm_forward_pass_partials.restype = i64
+    lib.cbfssm_forward_pass_partials.argtypes = [C.POINTER(Problem)]
+    lib.cbfssm_forward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10
+    lib.cbfssm_loglik_moments_f64.argtypes = [C.POINTER(Problem)] + [vp] * 9
+    lib.cbfssm_elbo_combine_f64.argtypes = [C.POINTER(Problem), dbl, dbl, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int or name.endswith('_f64') or name == 'cbfssm_gp_pack_layout':
+            fn.restype = ip
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cbfssm_last_error().decode('utf-8', 'replace')
+        raise CbfssmHipError('%s failed (rc=%d): %s' % (what, rc, msg))
+
+
+def pack_layout(M, D, Do):
+    lay = PackLayout()
+    check(load().cbfssm_gp_pack_layout(int(M), int(D), int(Do), C.byref(lay)), 'cbfssm_gp_pack_layout')
+    return lay
+
+
+def make_problem(B, S, T, dim_x, dim_u, dim_y, M, recog_len, k_factor, condition):
+    p = Problem()
+    p.B, p.S, p.T, p.dim_x, p.dim_u, p.dim_y, p.M = int(B), int(S), int(T), int(dim_x), int(dim_u), int(dim_y), int(M)
+    p.recog_len, p.condition, p.pad_, p.k_factor = int(recog_len), int(bool(condition)), 0, float(k_factor)
+    return p

@@ -1,0 +1,203 @@
+"""Tensor-level wrappers around the C ABI (PyTorch is used for device memory and streams only).
+
+All tensors are float64, contiguous, on one CUDA(=HIP) device.  Trajectories are time-major on the device
+(x: (T,N,dim_x), y2: (T,N,dim_x-dim_y), N = B*S, chain c = b*S + s); `as_btsd` gives the reference's (B,T,S,d) view.
+"""
+import ctypes as C
+import torch
+
+from . import lib as _l
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), 'need contiguous float64 CUDA tensor'
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f64(t, device):
+    return torch.as_tensor(t, dtype=torch.float64, device=device).contiguous()
+
+
+class GPPack:
+    """Loop-invariant operands of one GPModel on the device (include/cbfssm_hip.h: cbfssm_gp_prepare_f64)."""
+
+    def __init__(self, M, D, Do, device):
+        self.layout = _l.pack_layout(M, D, Do)
+        self.M, self.D, self.Do = M, D, Do
+        self.buf = torch.zeros(self.layout.total, dtype=torch.float64, device=device)
+
+    def prepare(self, Z, lengthscales, variance, zeta_mean, zeta_var, jitter=_l.JITTER):
+        dev = self.buf.device
+        Z, ls, var = _f64(Z, dev), _f64(lengthscales, dev).reshape(-1), _f64(variance, dev).reshape(-1)
+        zm, zv = _f64(zeta_mean, dev), _f64(zeta_var, dev)
+        assert Z.shape == (self.M, self.D) and ls.numel() == self.D and var.numel() == 1
+        assert zm.shape == (self.M, self.Do) and zv.shape == (self.M, self.Do)
+        rc = _l.load().cbfssm_gp_prepare_f64(C.byref(self.layout), _ptr(Z), _ptr(ls), _ptr(var), _ptr(zm), _ptr(zv),
+                                             float(jitter), _ptr(self.buf), _stream())
+        _l.check(rc, 'cbfssm_gp_prepare_f64')
+        return self
+
+    def section(self, name, shape):
+        off = getattr(self.layout, name)
+        n = 1
+        for s in shape:
+            n *= s
+        return self.buf[off:off + n].view(*shape)
+
+    @property
+    def scal(self):
+        return self.section('scal', (_l.SCAL_COUNT,))
+
+    @property
+    def L(self):
+        return self.section('L', (self.M, self.M))
+
+    @property
+    def Kmm(self):
+        return self.section('Kmm', (self.M, self.M))
+
+    @property
+    def Kinv(self):
+        return self.section('Kinv', (self.M, self.M))
+
+    def predict(self, X):
+        X = _f64(X, self.buf.device)
+        assert X.dim() == 2 and X.shape[1] == self.D
+        n = X.shape[0]
+        fmean = torch.empty(n, self.Do, dtype=torch.float64, device=X.device)
+        fvar = torch.empty_like(fmean)
+        rc = _l.load().cbfssm_gp_predict_f64(C.byref(self.layout), _ptr(self.buf), _ptr(X), n, _ptr(fmean),
+                                             _ptr(fvar), _stream())
+        _l.check(rc, 'cbfssm_gp_predict_f64')
+        return fmean, fvar
+
+
+def kmm_chol(Z, lengthscales, variance, jitter=_l.JITTER):
+    """RBF.K(zeta_pos) and cast_cholesky (gp_tf.py:33-65,129-130) -> (Kmm, L, info)."""
+    dev = Z.device
+    Z = _f64(Z, dev)
+    M, D = Z.shape
+    ls, var = _f64(lengthscales, dev).reshape(-1), _f64(variance, dev).reshape(-1)
+    Kmm = torch.empty(M, M, dtype=torch.float64, device=dev)
+    L = torch.empty_like(Kmm)
+    info = torch.zeros(1, dtype=torch.float64, device=dev)
+    work = torch.empty(2 * M * M + M * D, dtype=torch.float64, device=dev)
+    rc = _l.load().cbfssm_kmm_chol_f64(M, D, _ptr(Z), _ptr(ls), _ptr(var), float(jitter), _ptr(Kmm), _ptr(L),
+                                       _ptr(info), _ptr(work), _stream())
+    _l.check(rc, 'cbfssm_kmm_chol_f64')
+    return Kmm, L, info
+
+
+def as_btsd(x_tnd, B, S):
+    """(T, N, d) time-major device layout -> the reference's (B, T, S, d) view (cbfssm.py:95,181)."""
+    T, N, d = x_tnd.shape
+    return x_tnd.view(T, B, S, d).permute(1, 0, 2, 3)
+
+
+class ElboWorkspace:
+    """Device buffers of one ELBO evaluation for fixed (B, T) -- allocated once, reused every step."""
+
+    def __init__(self, prob, device, keep_h=False):
+        p = prob
+        N, T = p.B * p.S, p.T
+        dob = p.dim_x - p.dim_y
+        f = dict(dtype=torch.float64, device=device)
+        lib = _l.load()
+        self.n_ent = int(lib.cbfssm_backward_pass_partials(C.byref(p)))
+        self.n_kl = int(lib.cbfssm_forward_pass_partials(C.byref(p)))
+        self.y2 = torch.zeros(T, N, dob, **f)
+        self.h_all = torch.zeros(2, T, N, dob, **f) if keep_h else None
+        self.x = torch.zeros(T, N, p.dim_x, **f)
+        self.ent_part = torch.zeros(self.n_ent, **f)
+        self.kl_part = torch.zeros(self.n_kl, **f)
+        self.ll_part = torch.zeros(p.B * T * p.dim_y, **f)
+        self.pred_mean = torch.zeros(p.B, T, p.dim_y, **f)
+        self.pred_var = torch.zeros(p.B, T, p.dim_y, **f)
+        self.int_mean = torch.zeros(p.B, T, p.dim_x, **f)
+        self.int_var = torch.zeros(p.B, T, p.dim_x, **f)
+        self.out = torch.zeros(8, **f)
+
+
+def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, loss_factors, ws=None,
+                 keep_h=False):
+    """One forward evaluation of the ELBO (cbfssm.py:84-271) from prepared GP packs.  Asynchronous.
+
+    Returns the workspace; ws.out = [loglik, kl_x, entropy, kl_z_f, kl_z_b, elbo, loss, info].
+    """
+    lib = _l.load()
+    dev = u.device
+    if ws is None:
+        ws = ElboWorkspace(prob, dev, keep_h)
+    st = _stream()
+    pb = C.byref(prob)
+    N = prob.B * prob.S
+    assert u.shape == (prob.B, prob.T, prob.dim_u) and y.shape == (prob.B, prob.T, prob.dim_y)
+    assert hid_b.numel() == 2 * prob.T * N and eps_b.numel() == 2 * prob.T * N
+    assert eps_f.numel() == (prob.T - 1) * N
+    rc = lib.cbfssm_backward_pass_f64(pb, C.byref(pack_b.layout), _ptr(pack_b.buf), _ptr(var_x), _ptr(u), _ptr(y),
+                                      _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.ent_part), st)
+    _l.check(rc, 'cbfssm_backward_pass_f64')
+    rc = lib.cbfssm_forward_pass_f64(pb, C.byref(pack_f.layout), _ptr(pack_f.buf), _ptr(var_x), _ptr(var_y),
+                                     _ptr(u), _ptr(y), _ptr(ws.y2), _ptr(eps_f) if eps_f.numel() else None,
+                                     _ptr(ws.x), _ptr(ws.kl_part), st)
+    _l.check(rc, 'cbfssm_forward_pass_f64')
+    rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(var_y), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part), _ptr(ws.pred_mean),
+                                       _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)
+    _l.check(rc, 'cbfssm_loglik_moments_f64')
+    rc = lib.cbfssm_elbo_combine_f64(pb, float(loss_factors[0]), float(loss_factors[1]),
+                                     _ptr(ws.ll_part), ws.ll_part.numel(), _ptr(ws.kl_part), ws.kl_part.numel(),
+                                     _ptr(ws.ent_part), ws.ent_part.numel(), _ptr(pack_f.scal), _ptr(pack_b.scal),
+                                     _ptr(ws.out), st)
+    _l.check(rc, 'cbfssm_elbo_combine_f64')
+    return ws
+
+
+def tf_forward(x):
+    """softplus(x) + 1e-10, the positivity transform of every constrained quantity (tf_transform.py:19-21)."""
+    return torch.nn.functional.softplus(x, beta=1.0, threshold=1e9) + 1e-10
+
+
+class HipElbo:
+    """Forward-only ELBO evaluator on one device from the twelve unconstrained tensors (no autograd)."""
+
+    def __init__(self, config, device):
+        self.config = config
+        self.device = torch.device(device)
+        self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
+        self.M, self.S = config['ind_pnt_num'], config['samples']
+        D = self.dim_x + self.dim_u
+        self.pack_f = GPPack(self.M, D, self.dim_x, self.device)
+        self.pack_b = GPPack(self.M, D, self.dim_x - self.dim_y, self.device)
+        self._ws = {}
+
+    def prepare(self, params):
+        p = {k: _f64(v, self.device) for k, v in params.items()}
+        for g, pack in (('f', self.pack_f), ('b', self.pack_b)):
+            pack.prepare(p[g + '.zeta_pos'], tf_forward(p[g + '.lengthscales_unc']), tf_forward(p[g + '.variance_unc']),
+                         p[g + '.zeta_mean'], tf_forward(p[g + '.zeta_var_unc']))
+        self.var_x = tf_forward(p['var_x_unc']).contiguous()
+        self.var_y = tf_forward(p['var_y_unc']).contiguous()
+
+    def problem(self, B, T, condition):
+        c = self.config
+        return _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, c['recog_len'],
+                               c['k_factor'], condition)
+
+    def run(self, u, y, noise, condition=True, keep_h=False):
+        u, y = _f64(u, self.device), _f64(y, self.device)
+        B, T = u.shape[0], u.shape[1]
+        prob = self.problem(B, T, condition)
+        key = (B, T, keep_h)
+        if key not in self._ws:
+            self._ws[key] = ElboWorkspace(prob, self.device, keep_h)
+        ws = self._ws[key]
+        hid_b, eps_b, eps_f = (_f64(noise[k], self.device) for k in ('hid_b', 'eps_b', 'eps_f'))
+        elbo_forward(prob, self.pack_f, self.pack_b, self.var_x, self.var_y, u, y, hid_b, eps_b, eps_f,
+                     self.config['loss_factors'], ws)
+        return ws

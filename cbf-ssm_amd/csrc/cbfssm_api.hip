@@ -1,0 +1,494 @@
+// C ABI of the CBF-SSM ELBO hot path for MI355X (see include/cbfssm_hip.h) and the once-per-evaluation kernels:
+// K_mm build + Cholesky + inverse + operand packing + prior KL, log-likelihood/moments, ELBO combination.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdarg>
+#include "../../include/cbfssm_hip.h"
+#include "cbfssm_inst.hpp"
+
+CBF_FOR_EACH_NBLK(CBF_DECLARE)
+
+namespace cbfssm {
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-int(e) - 1000, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GP preparation: one workgroup per GPModel.
+//   K_mm (gp_tf.py:33-49,129), L = chol(K_mm + jitter I) (gp_tf.py:52-65,130), K^-1, operand images, prior_kl
+//   (gp_tf.py:163-172).
+// The factorisation is a right-looking Cholesky of the bordered matrix [[K, I], [I, 0]]: after M steps the
+// (1,1) block is L, the (2,1) block L^-T and the (2,2) block -K^-1 -- one pass, one barrier per column.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    int M, D, Do, NBLK, DK;
+    const double* Z;
+    const double* ls;
+    const double* var;
+    const double* zmean;   // may be null (kmm_chol only)
+    const double* zvar;
+    double jitter;
+    double* Kmm;           // M*M
+    double* A;             // M*M  -> L
+    double* G;             // M*M  -> L^-T
+    double* C;             // M*M  -> K^-1
+    double* Zs;            // M*D
+    // pack sections (null for kmm_chol only)
+    double* Bp;
+    double* Zp;
+    double* cz;
+    double* muA;
+    double* s2A;
+    double* invl;
+    double* scal;
+    double* info_out;      // kmm_chol: 1 double
+};
+
+#define PREP_NT 1024
+
+__global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs a)
+{
+    __shared__ double Xs[CBFSSM_MAX_M];
+    __shared__ double piv[CBFSSM_MAX_M];
+    __shared__ double red[PREP_NT / 64];
+    __shared__ int s_info;
+    const int tid = threadIdx.x;
+    const int M = a.M, D = a.D;
+    const int tx = tid & 31, ty = tid >> 5;   // 32 x 32 thread tile
+
+    if (tid == 0) s_info = 0;
+    // X / lengthscales and row norms (gp_tf.py:34-35)
+    for (int i = tid; i < M * D; i += PREP_NT) a.Zs[i] = a.Z[i] / a.ls[i % D];
+    __syncthreads();
+    for (int m = tid; m < M; m += PREP_NT) {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) s += a.Zs[m * D + j] * a.Zs[m * D + j];
+        Xs[m] = s;
+    }
+    __syncthreads();
+    const double var = a.var[0];
+    for (int i = ty; i < M; i += 32) {
+        for (int k = tx; k < M; k += 32) {
+            double dot = 0.0;
+            for (int j = 0; j < D; ++j) dot += a.Zs[i * D + j] * a.Zs[k * D + j];
+            const double d2 = -2.0 * dot + Xs[i] + Xs[k];                 // gp_tf.py:37-38, no clamp
+            const double kv = var * exp(-0.5 * d2);                       // gp_tf.py:49
+            a.Kmm[i * M + k] = kv;
+            a.A[i * M + k] = kv + ((i == k) ? a.jitter : 0.0);            // gp_tf.py:53
+            a.G[i * M + k] = (i == k) ? 1.0 : 0.0;
+            a.C[i * M + k] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    double logdet = 0.0;
+    for (int j = 0; j < M; ++j) {
+        const double p = a.A[j * M + j];
+        if (tid == 0) {
+            piv[j] = p;
+            if (!(p > 0.0) && s_info == 0) s_info = j + 1;
+            logdet += log(p);
+        }
+        const double rp = 1.0 / p;
+        // trailing update of K part (lower triangle, rows/cols > j)
+        for (int i = j + 1 + ty; i < M; i += 32) {
+            const double aij = a.A[i * M + j] * rp;
+            for (int k = j + 1 + tx; k <= i; k += 32) a.A[i * M + k] -= aij * a.A[k * M + j];
+        }
+        // border block G (rows <= j have a non-zero in column j)
+        for (int i = ty; i <= j; i += 32) {
+            const double gij = a.G[i * M + j] * rp;
+            for (int k = j + 1 + tx; k < M; k += 32) a.G[i * M + k] -= gij * a.A[k * M + j];
+        }
+        // Schur complement block C = -K^-1 accumulates (lower triangle)
+        for (int i = ty; i <= j; i += 32) {
+            const double gij = a.G[i * M + j] * rp;
+            for (int k = tx; k <= i; k += 32) a.C[i * M + k] -= gij * a.G[k * M + j];
+        }
+        __syncthreads();
+    }
+    // scale columns: L = A diag(piv)^-1/2, L^-T = G diag(piv)^-1/2; K^-1 = -C, symmetric
+    for (int i = ty; i < M; i += 32) {
+        for (int k = tx; k < M; k += 32) {
+            const double rs = 1.0 / sqrt(piv[k]);
+            const double lv = (k < i) ? a.A[i * M + k] * rs : ((k == i) ? sqrt(piv[k]) : 0.0);
+            const double gv = (k >= i) ? a.G[i * M + k] * rs : 0.0;
+            a.A[i * M + k] = lv;
+            a.G[i * M + k] = gv;
+            if (k > i) a.C[i * M + k] = -a.C[k * M + i];
+        }
+    }
+    __syncthreads();
+    for (int i = ty; i < M; i += 32)
+        for (int k = tx; k <= i; k += 32) a.C[i * M + k] = -a.C[i * M + k];
+    __syncthreads();
+    if (a.info_out && tid == 0) a.info_out[0] = double(s_info);
+    if (!a.Bp) return;
+
+    // ---- operand images for the time-loop kernels
+    const int Do = a.Do, NBLK = a.NBLK, DK = a.DK, Mp = 16 * NBLK, KS = Mp / 4;
+    for (int i = tid; i < NBLK * KS * 64; i += PREP_NT) {
+        const int l = i & 63, s = (i >> 6) % KS, rb = (i >> 6) / KS;
+        const int row = 16 * rb + (l & 15), col = 4 * s + (l >> 4);
+        a.Bp[i] = (row < M && col < M) ? a.C[row * M + col] : 0.0;
+    }
+    for (int i = tid; i < NBLK * DK * 64; i += PREP_NT) {
+        const int l = i & 63, s = (i >> 6) % DK, rb = (i >> 6) / DK;
+        const int row = 16 * rb + (l & 15), col = 4 * s + (l >> 4);
+        a.Zp[i] = (row < M && col < D) ? a.Zs[row * D + col] : 0.0;
+    }
+    const double logvar = log(var);
+    for (int m = tid; m < Mp; m += PREP_NT) a.cz[m] = (m < M) ? (-0.5 * Xs[m] + logvar) : -1e30;
+    for (int i = tid; i < NBLK * 4 * 64; i += PREP_NT) {
+        const int l = i & 63, r = (i >> 6) & 3, rb = i >> 8;
+        const int m = 16 * rb + 4 * r + (l >> 4), d = l & 15;
+        const bool ok = (m < M) && (d < Do);
+        a.muA[i] = ok ? a.zmean[m * Do + d] : 0.0;
+        a.s2A[i] = ok ? a.zvar[m * Do + d] : 0.0;
+    }
+    for (int j = tid; j < 4 * DK; j += PREP_NT) a.invl[j] = (j < D) ? 1.0 / a.ls[j] : 0.0;
+
+    // ---- prior KL: 0.5 sum_d [ tr(K^-1 S_d) + mu_d^T K^-1 mu_d - M + log det K - log det S_d ]   (gp_tf.py:163-172)
+    double acc = 0.0;
+    for (int i = tid; i < M * Do; i += PREP_NT) {
+        const int m = i / Do, d = i % Do;
+        double kmu = 0.0;
+        for (int k = 0; k < M; ++k) kmu += a.C[m * M + k] * a.zmean[k * Do + d];
+        const double s2 = a.zvar[m * Do + d];
+        acc += a.C[m * M + m] * s2 + a.zmean[m * Do + d] * kmu - log(s2);
+    }
+    const double tot = block_sum(acc, red, tid, PREP_NT);
+    if (tid == 0) {
+        a.scal[CBFSSM_SCAL_SIGMA2] = var;
+        a.scal[CBFSSM_SCAL_LOGDET] = logdet;
+        a.scal[CBFSSM_SCAL_KLZ] = 0.5 * (tot + double(Do) * (logdet - double(M)));
+        a.scal[CBFSSM_SCAL_INFO] = double(s_info);
+        for (int i = 4; i < CBFSSM_SCAL_COUNT; ++i) a.scal[i] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Log-likelihood and moments over particles (cbfssm.py:245-251,264-269).  One thread per (b, t, d).
+// ---------------------------------------------------------------------------------------------------------------------
+struct LlArgs {
+    int B, S, T, dim_x, dim_y;
+    const double* var_y;
+    const double* y;
+    const double* x;     // (T,N,dim_x)
+    double* ll_part;     // (B*T*dim_y)
+    double* pred_mean;   // (B,T,dim_y)
+    double* pred_var;
+    double* int_mean;    // (B,T,dim_x) or null
+    double* int_var;
+};
+
+__global__ void loglik_moments_kernel(LlArgs a)
+{
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t total = int64_t(a.B) * a.T * a.dim_x;
+    if (idx >= total) return;
+    const int d = int(idx % a.dim_x);
+    const int64_t bt = idx / a.dim_x;
+    const int t = int(bt % a.T), b = int(bt / a.T);
+    const int64_t N = int64_t(a.B) * a.S;
+    const double* xp = a.x + (int64_t(t) * N + int64_t(b) * a.S) * a.dim_x + d;
+    double sum = 0.0;
+    for (int s = 0; s < a.S; ++s) sum += xp[int64_t(s) * a.dim_x];
+    const double mean = sum / a.S;                                         // tf.nn.moments, cbfssm.py:267
+    double ss = 0.0;
+    for (int s = 0; s < a.S; ++s) {
+        const double dv = xp[int64_t(s) * a.dim_x] - mean;
+        ss += dv * dv;
+    }
+    const double var = ss / a.S;
+    if (a.int_mean) { a.int_mean[idx] = mean; a.int_var[idx] = var; }      // cbfssm.py:269
+    if (d < a.dim_y) {
+        const double vy = a.var_y[d];
+        const int64_t o = bt * a.dim_y + d;
+        a.pred_mean[o] = mean;
+        a.pred_var[o] = var + vy;                                          // cbfssm.py:268
+        // sum_s log N(y | x_s, vy) = -0.5 [ sum_s (y - x_s)^2 / vy + S (log 2 pi + log vy) ]   (cbfssm.py:247-251)
+        const double yo = a.y[o];
+        const double dm = yo - mean;
+        const double sq = ss + a.S * dm * dm;
+        a.ll_part[o] = -0.5 * (sq / vy + a.S * (1.8378770664093454836 + log(vy)));
+    }
+}
+
+struct CombineArgs {
+    const double* ll; int64_t n_ll;
+    const double* kl; int64_t n_kl;
+    const double* ent; int64_t n_ent;
+    const double* scal_f;
+    const double* scal_b;
+    double lambda0, lambda1, inv_s;
+    double* out;
+};
+
+__global__ __launch_bounds__(1024) void combine_kernel(CombineArgs a)
+{
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = tid; i < a.n_ll; i += 1024) s0 += a.ll[i];
+    for (int64_t i = tid; i < a.n_kl; i += 1024) s1 += a.kl[i];
+    for (int64_t i = tid; i < a.n_ent; i += 1024) s2 += a.ent[i];
+    const double loglik = block_sum(s0, red, tid, 1024);
+    const double kl_x = block_sum(s1, red, tid, 1024);
+    const double entropy = block_sum(s2, red, tid, 1024);
+    if (tid == 0) {
+        const double klf = a.scal_f[CBFSSM_SCAL_KLZ], klb = a.scal_b[CBFSSM_SCAL_KLZ];
+        // cbfssm.py:257-262
+        const double elbo = loglik * a.lambda0 * a.inv_s - kl_x * a.lambda0 * a.inv_s + entropy * a.lambda1 * a.inv_s
+                            - klf - klb;
+        a.out[0] = loglik; a.out[1] = kl_x; a.out[2] = entropy; a.out[3] = klf; a.out[4] = klb;
+        a.out[5] = elbo; a.out[6] = -elbo;
+        a.out[7] = fmax(a.scal_f[CBFSSM_SCAL_INFO], a.scal_b[CBFSSM_SCAL_INFO]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static const int kNblk[] = {1, 2, 4, 7, 10, 13, 16, 20};
+
+static int dispatch_predict(int NBLK, int DK, const PredictArgs& a, hipStream_t st)
+{
+    switch (NBLK) {
+#define X(NB) case NB: return launch_predict_nb##NB(DK, a, st);
+        CBF_FOR_EACH_NBLK(X)
+#undef X
+    }
+    return -2;
+}
+
+static int dispatch_pass(int NBLK, int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st)
+{
+    switch (NBLK) {
+#define X(NB) case NB: return launch_pass_nb##NB(DK, mode, a, grid, st);
+        CBF_FOR_EACH_NBLK(X)
+#undef X
+    }
+    return -2;
+}
+
+static PackPtrs pack_ptrs(const cbfssm_pack_layout* L, const double* pack)
+{
+    PackPtrs p;
+    p.Bp = pack + L->Bp; p.Zp = pack + L->Zp; p.cz = pack + L->cz; p.muA = pack + L->muA; p.s2A = pack + L->s2A;
+    p.invl = pack + L->invl; p.scal = pack + L->scal;
+    return p;
+}
+
+static int check_problem(const cbfssm_problem* p, const cbfssm_pack_layout* L, int Do)
+{
+    if (!p || !L) return fail(-1, "null problem/layout");
+    if (p->B < 1 || p->S < 1 || p->T < 1) return fail(-1, "B, S, T must be >= 1");
+    if (p->dim_x < 1 || p->dim_x > CBFSSM_MAX_DOUT) return fail(-1, "dim_x must be in [1,%d]", CBFSSM_MAX_DOUT);
+    if (p->dim_y < 0 || p->dim_y > p->dim_x || p->dim_u < 0) return fail(-1, "bad dim_y/dim_u");
+    if (p->recog_len < 1) return fail(-1, "recog_len must be >= 1");
+    if (L->D != p->dim_x + p->dim_u) return fail(-1, "pack D=%d != dim_x+dim_u=%d", L->D, p->dim_x + p->dim_u);
+    if (L->Do != Do) return fail(-1, "pack Do=%d, expected %d", L->Do, Do);
+    if (L->M != p->M) return fail(-1, "pack M=%d != problem M=%d", L->M, p->M);
+    if (int64_t(p->B) * p->S > (int64_t(1) << 30)) return fail(-1, "too many chains");
+    return 0;
+}
+
+static void bwd_segments(const cbfssm_problem* p, int* nseg0, int* nseg1)
+{
+    const int P = 2 * p->recog_len;
+    *nseg0 = p->T / P + 1;
+    *nseg1 = (p->T + p->recog_len) / P + 1;
+}
+
+}  // namespace cbfssm
+
+using namespace cbfssm;
+
+extern "C" {
+
+const char* cbfssm_last_error(void) { return g_err; }
+int cbfssm_version(void) { return 1; }
+
+int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out)
+{
+    if (!out) return fail(-1, "null layout");
+    if (M < 1 || M > CBFSSM_MAX_M) return fail(-1, "M=%d outside [1,%d]", M, CBFSSM_MAX_M);
+    if (D < 1 || D > 24) return fail(-1, "D=%d outside [1,24]", D);
+    if (Do < 1 || Do > CBFSSM_MAX_DOUT) return fail(-1, "Do=%d outside [1,%d]", Do, CBFSSM_MAX_DOUT);
+    int nblk = 0;
+    for (int v : kNblk) if (16 * v >= M) { nblk = v; break; }
+    const int dk = (D <= 8) ? 2 : ((D <= 16) ? 4 : 6);
+    memset(out, 0, sizeof(*out));
+    out->M = M; out->D = D; out->Do = Do; out->NBLK = nblk; out->DK = dk; out->Mp = 16 * nblk; out->Dp = 4 * dk;
+    out->KS = out->Mp / 4;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { int64_t r = o; o += (n + 63) / 64 * 64; return r; };
+    out->Bp = take(int64_t(nblk) * out->KS * 64);
+    out->Zp = take(int64_t(nblk) * dk * 64);
+    out->cz = take(out->Mp);
+    out->muA = take(int64_t(nblk) * 256);
+    out->s2A = take(int64_t(nblk) * 256);
+    out->invl = take(out->Dp);
+    out->scal = take(CBFSSM_SCAL_COUNT);
+    out->Kmm = take(int64_t(M) * M);
+    out->L = take(int64_t(M) * M);
+    out->Kinv = take(int64_t(M) * M);
+    out->Linvt = take(int64_t(M) * M);
+    out->Zs = take(int64_t(M) * D);
+    out->total = o;
+    return 0;
+}
+
+int cbfssm_kmm_chol_f64(int M, int D, const double* Z, const double* lengthscales, const double* variance,
+                        double jitter, double* Kmm, double* L, double* info, double* work, void* stream)
+{
+    if (M < 1 || M > CBFSSM_MAX_M || D < 1 || D > CBFSSM_MAX_DIN) return fail(-1, "bad M/D");
+    if (!Z || !lengthscales || !variance || !Kmm || !L || !info || !work) return fail(-1, "null pointer");
+    PrepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.D = D; a.Z = Z; a.ls = lengthscales; a.var = variance; a.jitter = jitter;
+    a.Kmm = Kmm; a.A = L; a.G = work; a.C = work + int64_t(M) * M; a.Zs = work + 2 * int64_t(M) * M;
+    a.info_out = info;
+    hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(PREP_NT), 0, (hipStream_t)stream, a);
+    return check_launch("kmm_chol");
+}
+
+int cbfssm_gp_prepare_f64(const cbfssm_pack_layout* L, const double* Z, const double* lengthscales,
+                          const double* variance, const double* zeta_mean, const double* zeta_var, double jitter,
+                          double* pack, void* stream)
+{
+    if (!L || !Z || !lengthscales || !variance || !zeta_mean || !zeta_var || !pack) return fail(-1, "null pointer");
+    PrepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = L->M; a.D = L->D; a.Do = L->Do; a.NBLK = L->NBLK; a.DK = L->DK;
+    a.Z = Z; a.ls = lengthscales; a.var = variance; a.zmean = zeta_mean; a.zvar = zeta_var; a.jitter = jitter;
+    a.Kmm = pack + L->Kmm; a.A = pack + L->L; a.G = pack + L->Linvt; a.C = pack + L->Kinv; a.Zs = pack + L->Zs;
+    a.Bp = pack + L->Bp; a.Zp = pack + L->Zp; a.cz = pack + L->cz; a.muA = pack + L->muA; a.s2A = pack + L->s2A;
+    a.invl = pack + L->invl; a.scal = pack + L->scal;
+    hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(PREP_NT), 0, (hipStream_t)stream, a);
+    return check_launch("gp_prepare");
+}
+
+int cbfssm_gp_predict_f64(const cbfssm_pack_layout* L, const double* pack, const double* X, int64_t npts,
+                          double* fmean, double* fvar, void* stream)
+{
+    if (!L || !pack || !X || !fmean || !fvar) return fail(-1, "null pointer");
+    if (npts < 0 || npts > (int64_t(1) << 34)) return fail(-1, "bad npts");
+    if (npts == 0) return 0;
+    PredictArgs a;
+    a.pk = pack_ptrs(L, pack); a.X = X; a.npts = npts; a.D = L->D; a.Do = L->Do; a.fmean = fmean; a.fvar = fvar;
+    int rc = dispatch_predict(L->NBLK, L->DK, a, (hipStream_t)stream);
+    if (rc) return fail(rc, "gp_predict launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
+    return 0;
+}
+
+int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p)
+{
+    if (!p || p->recog_len < 1) return -1;
+    int n0, n1;
+    bwd_segments(p, &n0, &n1);
+    const int64_t groups = (int64_t(p->B) * p->S + 15) / 16;
+    return groups * (n0 + n1);
+}
+
+int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_b,
+                             const double* var_x, const double* u, const double* y, const double* hid_b,
+                             const double* eps_b, double* y2, double* h_all, double* ent_part, void* stream)
+{
+    int rc = check_problem(p, L, p ? p->dim_x - p->dim_y : 0);
+    if (rc) return rc;
+    if (p->dim_x - p->dim_y < 1) return fail(-1, "backward pass needs dim_x > dim_y (use CBFSSMHALF otherwise)");
+    if (!pack_b || !var_x || !u || !y || !hid_b || !eps_b || !y2 || !ent_part) return fail(-1, "null pointer");
+    PassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pk = pack_ptrs(L, pack_b);
+    a.N = p->B * p->S; a.S = p->S; a.T = p->T; a.B = p->B;
+    a.dim_x = p->dim_x; a.dim_u = p->dim_u; a.dim_y = p->dim_y; a.Do = p->dim_x - p->dim_y; a.D = L->D;
+    a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = p->k_factor;
+    a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.y2_out = y2; a.h_all = h_all;
+    a.part_out = ent_part;
+    int n0, n1;
+    bwd_segments(p, &n0, &n1);
+    a.nseg0 = n0;
+    dim3 grid(unsigned((a.N + 15) / 16), unsigned(n0 + n1));
+    rc = dispatch_pass(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
+    if (rc) return fail(rc, "backward_pass launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
+    return 0;
+}
+
+int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p)
+{
+    if (!p) return -1;
+    return (int64_t(p->B) * p->S + 15) / 16;
+}
+
+int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                            const double* var_x, const double* var_y, const double* u, const double* y,
+                            const double* y2, const double* eps_f, double* x, double* kl_part, void* stream)
+{
+    int rc = check_problem(p, L, p ? p->dim_x : 0);
+    if (rc) return rc;
+    if (!pack_f || !var_x || !var_y || !u || !y || !x || !kl_part) return fail(-1, "null pointer");
+    if (p->dim_x > p->dim_y && !y2) return fail(-1, "y2 is null");
+    if (p->T > 1 && !eps_f) return fail(-1, "eps_f is null");
+    PassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pk = pack_ptrs(L, pack_f);
+    a.N = p->B * p->S; a.S = p->S; a.T = p->T; a.B = p->B;
+    a.dim_x = p->dim_x; a.dim_u = p->dim_u; a.dim_y = p->dim_y; a.Do = p->dim_x; a.D = L->D;
+    a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = p->k_factor;
+    a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x;
+    a.part_out = kl_part;
+    dim3 grid(unsigned((a.N + 15) / 16), 1);
+    rc = dispatch_pass(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
+    if (rc) return fail(rc, "forward_pass launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
+    return 0;
+}
+
+int cbfssm_loglik_moments_f64(const cbfssm_problem* p, const double* var_y, const double* y, const double* x,
+                              double* ll_part, double* pred_mean, double* pred_var, double* int_mean,
+                              double* int_var, void* stream)
+{
+    if (!p || !var_y || !y || !x || !ll_part || !pred_mean || !pred_var) return fail(-1, "null pointer");
+    if ((int_mean == nullptr) != (int_var == nullptr)) return fail(-1, "int_mean/int_var must both be given");
+    LlArgs a;
+    a.B = p->B; a.S = p->S; a.T = p->T; a.dim_x = p->dim_x; a.dim_y = p->dim_y;
+    a.var_y = var_y; a.y = y; a.x = x; a.ll_part = ll_part; a.pred_mean = pred_mean; a.pred_var = pred_var;
+    a.int_mean = int_mean; a.int_var = int_var;
+    const int64_t total = int64_t(p->B) * p->T * p->dim_x;
+    hipLaunchKernelGGL(loglik_moments_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return check_launch("loglik_moments");
+}
+
+int cbfssm_elbo_combine_f64(const cbfssm_problem* p, double lambda0, double lambda1, const double* ll_part,
+                            int64_t n_ll, const double* kl_part, int64_t n_kl, const double* ent_part, int64_t n_ent,
+                            const double* scal_f, const double* scal_b, double* out, void* stream)
+{
+    if (!p || !scal_f || !scal_b || !out) return fail(-1, "null pointer");
+    CombineArgs a;
+    a.ll = ll_part; a.n_ll = ll_part ? n_ll : 0; a.kl = kl_part; a.n_kl = kl_part ? n_kl : 0;
+    a.ent = ent_part; a.n_ent = ent_part ? n_ent : 0;
+    a.scal_f = scal_f; a.scal_b = scal_b; a.lambda0 = lambda0; a.lambda1 = lambda1; a.inv_s = 1.0 / p->S;
+    a.out = out;
+    hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    return check_launch("elbo_combine");
+}
+
+}  // extern "C"

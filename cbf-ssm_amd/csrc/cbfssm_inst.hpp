@@ -1,0 +1,108 @@
+// Per-NBLK instantiation of the time-loop kernels (one translation unit per NBLK so the build parallelises).
+#pragma once
+#include "cbfssm_kernels.hpp"
+
+namespace cbfssm {
+
+// How a tile of NBLK 16-row blocks of K^-1 is spread over the waves of a workgroup.
+//   NBLK <= 7  (M <= 112): one row block per wave, the wave's K^-1 rows stay in VGPRs for the whole pass.
+//   larger:                K^-1 is streamed from L2 as a pre-swizzled A-operand image (it no longer fits the
+//                          register file of a CU: 13 blocks x 52 k-steps x 2 VGPRs = 1352 of 2048).
+template <int NBLK>
+struct Cfg {
+    static constexpr int RB = (NBLK > 16) ? 2 : 1;
+    static constexpr bool BREG = (NBLK <= 7);
+};
+
+template <typename K>
+inline int set_lds(K kernel, size_t bytes)
+{
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
+        if (e != hipSuccess) return -int(e) - 1000;
+    }
+    return 0;
+}
+
+template <int NBLK, int DK>
+int launch_predict_t(const PredictArgs& a, hipStream_t st)
+{
+    typedef Cfg<NBLK> C;
+    typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
+    const size_t lds = TT::LDS_DOUBLES * sizeof(double);
+    auto k = predict_kernel<NBLK, C::RB, DK, C::BREG>;
+    int rc = set_lds(k, lds);
+    if (rc) return rc;
+    const unsigned groups = unsigned((a.npts + 15) / 16);
+    hipLaunchKernelGGL(k, dim3(groups), dim3(TT::NT), lds, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -int(e) - 1000;
+}
+
+template <int NBLK, int DK, int MODE>
+int launch_pass_t(const PassArgs& a, dim3 grid, hipStream_t st)
+{
+    typedef Cfg<NBLK> C;
+    typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
+    const size_t lds = TT::LDS_DOUBLES * sizeof(double);
+    auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE>;
+    int rc = set_lds(k, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -int(e) - 1000;
+}
+
+template <int NBLK>
+int launch_predict_n(int DK, const PredictArgs& a, hipStream_t st)
+{
+    switch (DK) {
+        case 2: return launch_predict_t<NBLK, 2>(a, st);
+        case 4: return launch_predict_t<NBLK, 4>(a, st);
+        case 6: return launch_predict_t<NBLK, 6>(a, st);
+    }
+    return -2;
+}
+
+template <int NBLK>
+int launch_pass_n(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st)
+{
+    if (mode == MODE_FWD) {
+        switch (DK) {
+            case 2: return launch_pass_t<NBLK, 2, MODE_FWD>(a, grid, st);
+            case 4: return launch_pass_t<NBLK, 4, MODE_FWD>(a, grid, st);
+            case 6: return launch_pass_t<NBLK, 6, MODE_FWD>(a, grid, st);
+        }
+    } else {
+        switch (DK) {
+            case 2: return launch_pass_t<NBLK, 2, MODE_BWD>(a, grid, st);
+            case 4: return launch_pass_t<NBLK, 4, MODE_BWD>(a, grid, st);
+            case 6: return launch_pass_t<NBLK, 6, MODE_BWD>(a, grid, st);
+        }
+    }
+    return -2;
+}
+
+}  // namespace cbfssm
+
+#define CBF_DECLARE(NB)                                                                          \
+    namespace cbfssm {                                                                           \
+    int launch_predict_nb##NB(int DK, const PredictArgs& a, hipStream_t st);                     \
+    int launch_pass_nb##NB(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st);      \
+    }
+
+#define CBF_INSTANTIATE(NB)                                                                      \
+    namespace cbfssm {                                                                           \
+    int launch_predict_nb##NB(int DK, const PredictArgs& a, hipStream_t st)                      \
+    {                                                                                            \
+        return launch_predict_n<NB>(DK, a, st);                                                  \
+    }                                                                                            \
+    int launch_pass_nb##NB(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st)       \
+    {                                                                                            \
+        return launch_pass_n<NB>(DK, mode, a, grid, st);                                         \
+    }                                                                                            \
+    }
+
+// the supported tile heights (16-row blocks of inducing points); M is padded up to the next one
+#define CBF_FOR_EACH_NBLK(X) X(1) X(2) X(4) X(7) X(10) X(13) X(16) X(20)

@@ -1,0 +1,2 @@
+#include "cbfssm_inst.hpp"
+CBF_INSTANTIATE(10)

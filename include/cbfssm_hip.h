@@ -1,0 +1,149 @@
+/*
+ * cbfssm_hip.h -- C ABI of the MI355X (gfx950) implementation of the CBF-SSM ELBO hot path.
+ *
+ * The reference (silvanmelchior/CBF-SSM) has no FFI / plugin interface: the path is Python graph-building code over
+ * TensorFlow ops.  Each entry point below therefore replaces a *set of TensorFlow op call sites*; the cited
+ * file:line ranges are relative to the reference repository root.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer to contiguous row-major float64 unless marked "host";
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never allocates, never synchronises;
+ *   - return value: 0 = OK, <0 = argument / launch error (text in cbfssm_last_error(), thread local);
+ *   - numerical failure of the Cholesky (leading minor not positive definite; TensorFlow raises
+ *     InvalidArgumentError there) is reported asynchronously in pack[scal + CBFSSM_SCAL_INFO] (k>0 = minor k);
+ *   - chains: N = B*S particle chains, chain index c = b*S + s; trajectories are kept TIME-MAJOR on the device:
+ *     x[t][c][d], y2[t][c][d] (the reference's (B,T,S,d) tensors are stride-permuted views of these).
+ */
+#ifndef CBFSSM_HIP_H
+#define CBFSSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBFSSM_MAX_DOUT 16   /* GP output dimension (dim_x) handled by one 16-row MFMA block */
+#define CBFSSM_MAX_DIN 64    /* GP input dimension dim_x + dim_u */
+#define CBFSSM_MAX_M 320     /* inducing points */
+
+/* indices into the scalar block of a GP pack */
+enum {
+    CBFSSM_SCAL_SIGMA2 = 0,  /* kernel variance */
+    CBFSSM_SCAL_LOGDET = 1,  /* log det (K_mm + jitter I) */
+    CBFSSM_SCAL_KLZ = 2,     /* prior_kl() */
+    CBFSSM_SCAL_INFO = 3,    /* 0 = OK, k>0 = leading minor k not positive definite */
+    CBFSSM_SCAL_COUNT = 8
+};
+
+/* Offsets (in doubles) of the sections of one GP pack; filled by cbfssm_gp_pack_layout (host struct). */
+typedef struct {
+    int64_t total;    /* doubles to allocate */
+    int64_t Bp;       /* [NBLK][KS][64]  K^-1 as MFMA A-operand image, zero padded to Mp = 16*NBLK           */
+    int64_t Zp;       /* [NBLK][DK][64]  Z/lengthscale as MFMA A-operand image                               */
+    int64_t cz;       /* [Mp]            -0.5|z~|^2 + log sigma^2 (padding rows: -1e30)                      */
+    int64_t muA;      /* [NBLK][4][64]   zeta_mean as A-operand image of the epilogue product                */
+    int64_t s2A;      /* [NBLK][4][64]   zeta_var  as A-operand image                                        */
+    int64_t invl;     /* [Dp]            1/lengthscale, zero padded                                          */
+    int64_t scal;     /* [CBFSSM_SCAL_COUNT]                                                                 */
+    int64_t Kmm;      /* [M][M]          kernel matrix, no jitter          (gp_tf.py:129)                    */
+    int64_t L;        /* [M][M]          lower Cholesky factor             (gp_tf.py:130)                    */
+    int64_t Kinv;     /* [M][M]          (K_mm + jitter I)^-1                                                */
+    int64_t Linvt;    /* [M][M]          L^-T (upper triangular), by-product of the factorisation            */
+    int64_t Zs;       /* [M][D]          Z / lengthscale                                                     */
+    int32_t M, D, Do, NBLK, DK, Mp, Dp, KS;
+} cbfssm_pack_layout;
+
+/* Problem description shared by the pass kernels (host struct, passed by pointer). */
+typedef struct {
+    int32_t B, S, T;            /* sequences, particles per sequence, time steps                             */
+    int32_t dim_x, dim_u, dim_y;
+    int32_t M;                  /* inducing points                                                           */
+    int32_t recog_len;          /* config['recog_len']      cbfssm.py:120,190                                */
+    int32_t condition;          /* feed of model.condition  cbfssm.py:227                                    */
+    int32_t pad_;
+    double k_factor;            /* config['k_factor']       cbfssm.py:191,214                                */
+} cbfssm_problem;
+
+const char* cbfssm_last_error(void);
+int cbfssm_version(void);
+
+/* Layout of a GP pack for (M, D = dim_x + dim_u, Do).  Host only. */
+int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out);
+
+/*
+ * K_mm and its Cholesky factor.
+ * Replaces: RBF.K(zeta_pos) (gp_tf.py:33-49,129) and cast_cholesky/_jitter_cholesky (gp_tf.py:52-65,130).
+ *   Z (M,D), lengthscales (D), variance (1)  ->  Kmm (M,M) without jitter, L (M,M) lower (upper part zero),
+ *   info (1 double: 0 or the failing leading minor).  work: >= 3*M*M doubles.
+ */
+int cbfssm_kmm_chol_f64(int M, int D, const double* Z, const double* lengthscales, const double* variance,
+                        double jitter, double* Kmm, double* L, double* info, double* work, void* stream);
+
+/*
+ * Everything that is loop invariant for one GPModel, once per ELBO evaluation.
+ * Replaces: GPModel.__init__ tail (gp_tf.py:129-130), the operand preparation of GPModel.predict
+ * (gp_tf.py:134-159: X/lengthscales, K^-1 instead of two triangular solves) and GPModel.prior_kl (gp_tf.py:163-172).
+ *   inputs are the *constrained* values: Z (M,D), lengthscales (D), variance (1), zeta_mean (M,Do), zeta_var (M,Do)
+ *   pack: layout.total doubles.
+ */
+int cbfssm_gp_prepare_f64(const cbfssm_pack_layout* layout, const double* Z, const double* lengthscales,
+                          const double* variance, const double* zeta_mean, const double* zeta_var,
+                          double jitter, double* pack, void* stream);
+
+/*
+ * GPModel.predict(Xnew) (gp_tf.py:132-161): X (npts, D) -> fmean (npts, Do), fvar (npts, Do).
+ */
+int cbfssm_gp_predict_f64(const cbfssm_pack_layout* layout, const double* pack, const double* X, int64_t npts,
+                          double* fmean, double* fvar, void* stream);
+
+/*
+ * Both backward (recognition) runs, CBFSSM._backward/_backward_run/_backward_body (cbfssm.py:84-158).
+ *   u (B,T,dim_u), y (B,T,dim_y), hid_b (2,T,N), eps_b (2,T,N), var_x (dim_x)
+ *   -> y2 (T,N,dim_x-dim_y)  [every t written by exactly one run, cbfssm.py:123-128,151]
+ *      h_all (2,T,N,dim_x-dim_y) or NULL: every step's output of both runs (kept for the adjoint)
+ *      ent_part (n_ent_part doubles): per-workgroup partial sums of 0.5*sum(log(2 pi e) + log fvar) over the
+ *      written steps (cbfssm.py:154-156); their sum is `entropy` (cbfssm.py:99).
+ *   cbfssm_backward_pass_partials(problem) gives n_ent_part.
+ */
+int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p);
+int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const double* pack_b,
+                             const double* var_x, const double* u, const double* y, const double* hid_b,
+                             const double* eps_b, double* y2, double* h_all, double* ent_part, void* stream);
+
+/*
+ * Forward (filter) pass, CBFSSM._forward/_forward_body (cbfssm.py:160-237).
+ *   y2 (T,N,dim_x-dim_y) from the backward pass, eps_f (T-1,N), var_x (dim_x), var_y (dim_x)
+ *   -> x (T,N,dim_x)   [x[0] = y_tilde[0], cbfssm.py:168]
+ *      kl_part (n_kl_part doubles): per-workgroup partial sums of kl_reg (cbfssm.py:232-235); sum = kl_x.
+ */
+int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p);
+int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
+                            const double* var_x, const double* var_y, const double* u, const double* y,
+                            const double* y2, const double* eps_f, double* x, double* kl_part, void* stream);
+
+/*
+ * Log-likelihood and predictive moments, CBFSSM._build_loss (cbfssm.py:245-251) and _build_prediction
+ * (cbfssm.py:264-269).
+ *   x (T,N,dim_x), y (B,T,dim_y), var_y (dim_x)
+ *   -> ll_part (B*T doubles: log-lik summed over particles per (b,t)), pred_mean (B,T,dim_y), pred_var (B,T,dim_y),
+ *      int_mean (B,T,dim_x) / int_var (B,T,dim_x) or NULL.
+ */
+int cbfssm_loglik_moments_f64(const cbfssm_problem* p, const double* var_y, const double* y, const double* x,
+                              double* ll_part, double* pred_mean, double* pred_var, double* int_mean,
+                              double* int_var, void* stream);
+
+/*
+ * ELBO combination, CBFSSM._build_loss (cbfssm.py:257-262): deterministic sums of the partial buffers.
+ *   out[0..7] = loglik, kl_x, entropy, kl_z_f, kl_z_b, elbo, loss, info (max of the two packs' info).
+ */
+int cbfssm_elbo_combine_f64(const cbfssm_problem* p, double lambda0, double lambda1,
+                            const double* ll_part, int64_t n_ll, const double* kl_part, int64_t n_kl,
+                            const double* ent_part, int64_t n_ent, const double* scal_f, const double* scal_b,
+                            double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

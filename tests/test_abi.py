@@ -1,0 +1,38 @@
+"""CPU-side checks of the C-ABI library: it loads and exports every symbol include/cbfssm_hip.h declares.
+(No compute calls here: those need a GPU and live in test_hip_parity.py.)"""
+import ctypes
+import os
+import re
+
+from cbfssm.hip import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'cbfssm_hip.h')).read()
+    return sorted(set(re.findall(r'\b(cbfssm_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(lib.LIB_PATH), 'run __graft_entry__.build() first'
+    so = ctypes.CDLL(lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert set(declared) == set(lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(so, name), name
+
+
+def test_layout_is_host_only_and_consistent():
+    lay = lib.pack_layout(100, 21, 14)
+    assert (lay.NBLK, lay.DK, lay.Mp, lay.KS) == (7, 6, 112, 28)
+    assert lay.total > lay.Zs >= lay.Linvt + 100 * 100
+    lay = lib.pack_layout(300, 6, 4)
+    assert (lay.NBLK, lay.DK) == (20, 2)
+    for bad in ((0, 5, 4), (321, 5, 4), (10, 25, 4), (10, 5, 17)):
+        try:
+            lib.pack_layout(*bad)
+            assert False, bad
+        except lib.CbfssmHipError:
+            pass
+    assert lib.load().cbfssm_version() >= 1
