@@ -1,0 +1,229 @@
+"""ELBO-step throughput of the MI355X CBF-SSM hot path (BASELINE.json metric) -- prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--mode eval|train]
+
+A "step" is one pass of the hot path over one synthetic mini-batch already resident in HBM: noise draw, positivity
+transforms, K_mm/Cholesky/K^-1 + operand packing for both GPs, both backward (recognition) runs, the forward
+(filter) pass, log-likelihood + moments, ELBO combination (mode=eval: what Trainer's test pass runs,
+reference training/trainer.py:46) and, for mode=train, the adjoint pass + Adam update (trainer.py:40).
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank holds the same per-GPU workload
+(weak scaling: the global batch is N x B sequences) and the ranks exchange one all-reduce per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'cbf-ssm_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (spec); csrc/probe/mfma_f64_probe measures 77.7 on the box
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(w, seconds_budget=20.0, threads=16):
+    """The op-for-op PyTorch-CPU float64 restatement (oracle/cbfssm_torch_ref.py) on the host cores, on a bounded
+    sample: the same workload with T truncated (cost is exactly linear in the number of GP calls 3T-1)."""
+    from cbfssm import synthetic as syn
+    from oracle import cbfssm_torch_ref as tref
+    import dataclasses
+    torch.set_num_threads(threads)
+    T_s = min(w.T, 8)
+    ws = dataclasses.replace(w, T=T_s, recog_len=min(w.recog_len, 2))
+    cfg = ws.model_config()
+    p = {k: torch.tensor(v) for k, v in syn.make_params(ws).items()}
+    u, y = (torch.tensor(a) for a in syn.make_inputs(ws))
+    noise = {k: torch.tensor(v) for k, v in syn.make_noise(ws).items()}
+    times = []
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        for i in range(5):
+            t0 = time.perf_counter()
+            tref.elbo_step(cfg, p, u, y, noise, True)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > seconds_budget and i >= 1:
+                break
+    t_sample = float(np.median(times[1:] if len(times) > 1 else times))
+    scale = (3 * w.T - 1) / (3 * T_s - 1)
+    t_full = t_sample * scale
+    return {'value': 1.0 / t_full, 'unit': 'steps/s', 'cores': threads, 'kind': 'port',
+            'sample': 'eval step of %s with T truncated to %d (%d of %d GP calls), median of %d runs = %.3f s, '
+                      'scaled linearly to T=%d; PyTorch-CPU float64 restatement of the TF-1.8 op sequence, %d threads'
+                      % (w.name, T_s, 3 * T_s - 1, 3 * w.T - 1, max(1, len(times) - 1), t_sample, w.T, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='C3')
+    ap.add_argument('--mode', default='auto', choices=['auto', 'eval', 'train'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from cbfssm import synthetic as syn
+    from cbfssm.hip import ops, lib
+    lib.load()   # fail loudly if the HIP extension is missing
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    w = syn.WORKLOADS[args.workload]
+    cfg = w.model_config()
+    mode = args.mode
+    try:
+        from cbfssm.hip.train import HipTrainStep
+        have_train = True
+    except ImportError:
+        have_train = False
+    if mode == 'auto':
+        mode = 'train' if have_train else 'eval'
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    u = torch.randn(w.B, w.T, w.dim_u, dtype=torch.float64, device=dev, generator=g)
+    y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=dev, generator=g)
+    params = {k: torch.tensor(v, device=dev) for k, v in syn.make_params(w, seed=1).items()}
+    N = w.N
+    noise_buf = torch.empty(2 * w.T * N * 2 + (w.T - 1) * N, dtype=torch.float64, device=dev)
+
+    def draw_noise():
+        noise_buf.normal_(generator=g)
+        a = 2 * w.T * N
+        return {'hid_b': noise_buf[:a], 'eps_b': noise_buf[a:2 * a], 'eps_f': noise_buf[2 * a:]}
+
+    red = torch.zeros(8, dtype=torch.float64, device=dev)
+    if mode == 'train':
+        stepper = HipTrainStep(cfg, params, dev, dist if world > 1 else None)
+
+        def step():
+            return stepper.step(u, y, draw_noise(), condition=True)
+    else:
+        eng = ops.HipElbo(cfg, dev)
+
+        def step():
+            eng.prepare(params)
+            ws = eng.run(u, y, draw_noise(), condition=True)
+            if world > 1:
+                red.copy_(ws.out)
+                dist.all_reduce(red)       # data terms of the ELBO summed over ranks (RCCL over xGMI)
+            return ws.out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = float(out[6]) if mode == 'eval' else float(out)
+    assert np.isfinite(loss), 'non-finite loss'
+
+    # ---- per-kernel timing of the two time-loop kernels with HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        eng2 = ops.HipElbo(cfg, dev)
+        eng2.prepare(params)
+        noise = draw_noise()
+        prob = eng2.problem(w.B, w.T, True)
+        ws = ops.ElboWorkspace(prob, dev, keep_h=False)
+        import ctypes as C
+        l = lib.load()
+        st = ops._stream()
+
+        def time_kernel(fn, reps=10):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        def k_bwd():
+            lib.check(l.cbfssm_backward_pass_f64(C.byref(prob), C.byref(eng2.pack_b.layout), ops._ptr(eng2.pack_b.buf),
+                                                 ops._ptr(eng2.var_x), ops._ptr(u), ops._ptr(y),
+                                                 ops._ptr(noise['hid_b']), ops._ptr(noise['eps_b']), ops._ptr(ws.y2),
+                                                 None, ops._ptr(ws.ent_part), st), 'bwd')
+
+        def k_fwd():
+            lib.check(l.cbfssm_forward_pass_f64(C.byref(prob), C.byref(eng2.pack_f.layout), ops._ptr(eng2.pack_f.buf),
+                                                ops._ptr(eng2.var_x), ops._ptr(eng2.var_y), ops._ptr(u), ops._ptr(y),
+                                                ops._ptr(ws.y2), ops._ptr(noise['eps_f']), ops._ptr(ws.x),
+                                                ops._ptr(ws.kl_part), st), 'fwd')
+
+        def F(M, D, Do):   # algorithmic FLOPs of one GP point evaluation
+            return 2 * M * M + M * (2 * D + 5 * Do + 5)
+        t_b, t_f = time_kernel(k_bwd), time_kernel(k_fwd)
+        fl_b = 2.0 * w.T * N * F(w.M, w.D, w.dim_out_b)
+        fl_f = 1.0 * (w.T - 1) * N * F(w.M, w.D, w.dim_x)
+        name, tk, fl = ('backward_pass (pass_kernel MODE_BWD)', t_b, fl_b) if t_b >= t_f else \
+                       ('forward_pass (pass_kernel MODE_FWD)', t_f, fl_f)
+        ach = fl / tk / 1e12
+        roof = {'bound': 'mfma', 'achieved': ach, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': None, 'kernel': name,
+                'kernel_ms': {'backward_pass': t_b * 1e3, 'forward_pass': t_f * 1e3},
+                'kernel_tflops': {'backward_pass': fl_b / t_b / 1e12, 'forward_pass': fl_f / t_f / 1e12},
+                'hbm_algorithmic_GBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9,
+                'hbm_frac_of_8TBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
+
+    if rank == 0:
+        steps_per_s = args.steps / dt
+        rec = {
+            'metric': 'ELBO steps/sec', 'value': steps_per_s * world, 'unit': 'steps/s (one step = one %d-sequence '
+                      'mini-batch per GPU)' % w.B,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'states_per_sec': steps_per_s * world * w.B * w.T,
+            'config': {'workload': '%s %s step: M=%d T=%d B=%d/GPU S=%d dim_x=%d dim_u=%d dim_y=%d recog_len=%d'
+                                   % (w.name, mode, w.M, w.T, w.B, w.S, w.dim_x, w.dim_u, w.dim_y, w.recog_len),
+                       'mode': mode, 'global_batch': w.B * world, 'seq_len': w.T, 'particles': w.S,
+                       'parallelism': 'dp%d' % world},
+            'loss': loss,
+            'roofline': roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            rec['cpu_baseline'] = cpu_baseline(w)
+            if mode == 'train':
+                rec['cpu_baseline']['sample'] += ' (eval step; a train step costs ~3x on either side)'
+            rec['speedup_vs_cpu_baseline'] = rec['value'] / rec['cpu_baseline']['value']
+        else:
+            rec['cpu_baseline'] = None
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
