@@ -17,14 +17,15 @@ SYMBOLS = (
     'cbfssm_last_error', 'cbfssm_version', 'cbfssm_gp_pack_layout', 'cbfssm_kmm_chol_f64', 'cbfssm_gp_prepare_f64',
     'cbfssm_gp_predict_f64', 'cbfssm_backward_pass_partials', 'cbfssm_backward_pass_f64',
     'cbfssm_forward_pass_partials', 'cbfssm_forward_pass_f64', 'cbfssm_loglik_moments_f64',
-    'cbfssm_elbo_combine_f64',
+    'cbfssm_elbo_combine_f64', 'cbfssm_rev_workgroups', 'cbfssm_forward_pass_bwd_f64',
+    'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64',
 )
 
 
 class PackLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('total', 'Bp', 'Zp', 'cz', 'muA', 's2A', 'invl', 'scal', 'Kmm', 'L', 'Kinv',
-                                          'Linvt', 'Zs')] + \
-               [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS')]
+                                          'Linvt', 'Zs', 'muB', 's2B', 'ZT', 'rev_slab')] + \
+               [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS', 'JB', 'pad_')]
 
 
 class Problem(C.Structure):
@@ -64,6 +65,11 @@ def load():
     lib.cbfssm_forward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10
     lib.cbfssm_loglik_moments_f64.argtypes = [C.POINTER(Problem)] + [vp] * 9
     lib.cbfssm_elbo_combine_f64.argtypes = [C.POINTER(Problem), dbl, dbl, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp]
+    lib.cbfssm_rev_workgroups.restype = i64
+    lib.cbfssm_rev_workgroups.argtypes = [C.POINTER(Problem), ip]
+    lib.cbfssm_forward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, vp, vp]
+    lib.cbfssm_backward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, vp]
+    lib.cbfssm_reduce_partials_f64.argtypes = [vp, i64, i64, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int or name.endswith('_f64') or name == 'cbfssm_gp_pack_layout':

@@ -1,0 +1,265 @@
+"""Loss + gradient of the CBF-SSM ELBO on the HIP path, and the Adam train step (cbfssm/model/cbfssm.py:273-275).
+
+The time-loop adjoints run in the hand-written kernels (csrc/cbfssm_adjoint.hpp); this module is the glue the
+north_star leaves in Python: the positivity transforms and their chain rule, the O(M^3) once-per-step adjoint of
+K_mm -> Cholesky -> K^-1 (a handful of M x M float64 matmuls), the prior-KL gradient, the data-parallel
+all-reduce and the optimizer update.
+
+Multi-GPU (one process per GPU): every rank evaluates its own mini-batch shard; the ranks exchange ONE all-reduce
+per step over a flat float64 buffer [reduced adjoint slab of gp_f | slab of gp_b | loglik, kl_x, entropy, ...].
+The prior-KL terms and their gradients are rank-invariant and are added once after the reduce, so the result
+equals a single-device evaluation of the global batch (cbfssm.py:257-261 sums over the batch).
+"""
+import ctypes as C
+import math
+import torch
+
+from . import lib as _l
+from . import ops
+from .ops import _ptr, _stream, _f64, tf_forward, GPPack
+
+PARAM_NAMES = (
+    'f.zeta_pos', 'f.zeta_mean', 'f.zeta_var_unc', 'f.variance_unc', 'f.lengthscales_unc',
+    'b.zeta_pos', 'b.zeta_mean', 'b.zeta_var_unc', 'b.variance_unc', 'b.lengthscales_unc',
+    'var_x_unc', 'var_y_unc',
+)
+LOG2PI = math.log(2.0 * math.pi)
+
+
+def _unpack_c(v, nrb, ncb):
+    """MFMA accumulator image [rb][cb][r][lane] -> dense (16*nrb, 16*ncb); row = 16rb + (lane>>4) + 4r."""
+    return v.view(nrb, ncb, 4, 4, 16).permute(0, 2, 3, 1, 4).reshape(16 * nrb, 16 * ncb)
+
+
+class HipElboGrad:
+    """loss and d loss / d (12 unconstrained tensors) for one mini-batch on one device."""
+
+    def __init__(self, config, device, dist=None):
+        self.config = config
+        self.device = torch.device(device)
+        self.dist = dist
+        self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
+        self.M, self.S = config['ind_pnt_num'], config['samples']
+        self.D = self.dim_x + self.dim_u
+        self.dob = self.dim_x - self.dim_y
+        self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device)
+        self.pack_b = GPPack(self.M, self.D, self.dob, self.device)
+        for pk in (self.pack_f, self.pack_b):
+            if pk.layout.rev_slab <= 0:
+                raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d): training supports M <= 112 in '
+                                        'this build' % (self.M, pk.layout.NBLK))
+        self.slab_f = int(self.pack_f.layout.rev_slab)
+        self.slab_b = int(self.pack_b.layout.rev_slab)
+        # flat reduce buffer: [slab_f | slab_b | loglik, kl_x, entropy, gvy_ll[dim_y]]
+        self.nred = self.slab_f + self.slab_b + 3 + self.dim_y
+        self.red = torch.zeros(self.nred, dtype=torch.float64, device=self.device)
+        self._ws = {}
+
+    # ---- forward evaluation (keeps what the adjoint needs)
+    def _constrained(self, p):
+        c = {}
+        for g in 'fb':
+            c[g + '.ls'] = tf_forward(p[g + '.lengthscales_unc']).reshape(-1).contiguous()
+            c[g + '.var'] = tf_forward(p[g + '.variance_unc']).reshape(-1).contiguous()
+            c[g + '.zvar'] = tf_forward(p[g + '.zeta_var_unc']).contiguous()
+        c['var_x'] = tf_forward(p['var_x_unc']).contiguous()
+        c['var_y'] = tf_forward(p['var_y_unc']).contiguous()
+        return c
+
+    def _workspace(self, prob):
+        key = (prob.B, prob.T)
+        if key not in self._ws:
+            ws = ops.ElboWorkspace(prob, self.device, keep_h=True)
+            lib = _l.load()
+            n_f = int(lib.cbfssm_rev_workgroups(C.byref(prob), 0))
+            n_b = int(lib.cbfssm_rev_workgroups(C.byref(prob), 1))
+            f = dict(dtype=torch.float64, device=self.device)
+            ws.gy2 = torch.zeros_like(ws.y2)
+            ws.gpart_f = torch.zeros(n_f * self.slab_f, **f)
+            ws.gpart_b = torch.zeros(n_b * self.slab_b, **f)
+            ws.n_f, ws.n_b = n_f, n_b
+            self._ws[key] = ws
+        return self._ws[key]
+
+    def loss_and_grads(self, params, u, y, noise, condition=True):
+        """params: dict of unconstrained float64 device tensors.  Returns (loss 0-d tensor, grads dict, terms)."""
+        lib = _l.load()
+        dev = self.device
+        cfg = self.config
+        p = {k: _f64(params[k], dev) for k in PARAM_NAMES}
+        u, y = _f64(u, dev), _f64(y, dev)
+        B, T = u.shape[0], u.shape[1]
+        prob = _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, cfg['recog_len'],
+                               cfg['k_factor'], condition)
+        c = self._constrained(p)
+        self.pack_f.prepare(p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar'])
+        self.pack_b.prepare(p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar'])
+        ws = self._workspace(prob)
+        hid_b, eps_b, eps_f = (_f64(noise[k], dev) for k in ('hid_b', 'eps_b', 'eps_f'))
+        lf = cfg['loss_factors']
+        ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws)
+
+        # ---- adjoint time loops
+        st = _stream()
+        pb = C.byref(prob)
+        cL, cE = float(lf[0]) / self.S, float(lf[1]) / self.S
+        rc = lib.cbfssm_forward_pass_bwd_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf), _ptr(c['var_x']),
+                                             _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
+                                             _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), cL, _ptr(ws.gy2),
+                                             _ptr(ws.gpart_f), st)
+        _l.check(rc, 'cbfssm_forward_pass_bwd_f64')
+        rc = lib.cbfssm_backward_pass_bwd_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
+                                              _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
+                                              _ptr(ws.h_all), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), st)
+        _l.check(rc, 'cbfssm_backward_pass_bwd_f64')
+        red = self.red
+        sf, sb = self.slab_f, self.slab_b
+        _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
+        _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
+
+        # ---- data scalars and the log-likelihood's pull on var_y (cbfssm.py:245-251)
+        vy = c['var_y'][:self.dim_y]
+        ll_d = ws.ll_part.view(B * T, self.dim_y).sum(0)
+        sq_d = (-2.0 * ll_d - B * T * self.S * (LOG2PI + torch.log(vy))) * vy
+        gvy_ll = -cL * 0.5 * (sq_d / (vy * vy) - B * T * self.S / vy)
+        tail = red[sf + sb:]
+        tail[0:3] = ws.out[0:3]
+        tail[3:] = gvy_ll
+        if self.dist is not None:
+            self.dist.all_reduce(red)          # the one collective of a train step (RCCL over xGMI)
+
+        # ---- once-per-step adjoints and the chain through the positivity transforms
+        grads = {}
+        gvx = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
+        gvy = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
+        for g, pack, slab, Do in (('f', self.pack_f, red[:sf], self.dim_x), ('b', self.pack_b, red[sf:sf + sb], self.dob)):
+            gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(pack, slab, p[g + '.zeta_pos'], c[g + '.ls'], c[g + '.var'],
+                                                              p[g + '.zeta_mean'], c[g + '.zvar'], Do)
+            grads[g + '.zeta_pos'] = gz
+            grads[g + '.zeta_mean'] = gmu
+            grads[g + '.zeta_var_unc'] = gs2 * torch.sigmoid(p[g + '.zeta_var_unc'])
+            grads[g + '.variance_unc'] = (gvar * torch.sigmoid(p[g + '.variance_unc'])).reshape(p[g + '.variance_unc'].shape)
+            grads[g + '.lengthscales_unc'] = gls * torch.sigmoid(p[g + '.lengthscales_unc'])
+            gvx[:Do] += small[0:Do]
+            if g == 'f':
+                gvy += small[16:16 + self.dim_x]
+        gvy[:self.dim_y] += tail[3:]
+        grads['var_x_unc'] = gvx * torch.sigmoid(p['var_x_unc'])
+        grads['var_y_unc'] = gvy * torch.sigmoid(p['var_y_unc'])
+
+        loglik, kl_x, entropy = tail[0], tail[1], tail[2]
+        kl_z_f, kl_z_b = self.pack_f.scal[_l.SCAL_KLZ], self.pack_b.scal[_l.SCAL_KLZ]
+        elbo = loglik * cL - kl_x * cL + entropy * cE - kl_z_f - kl_z_b                    # cbfssm.py:258-261
+        terms = {'loglik': loglik, 'kl_x': kl_x, 'entropy': entropy, 'kl_z_f': kl_z_f, 'kl_z_b': kl_z_b,
+                 'info': ws.out[7]}
+        return -elbo, grads, terms
+
+    def _gp_adjoint(self, pack, slab, Z, ls, var, zmean, zvar, Do):
+        """Adjoint of gp_prepare (K_mm -> chol -> K^-1, operand scaling, prior KL) given the reduced data slab."""
+        lay = pack.layout
+        M, D, NBLK, JB = self.M, self.D, lay.NBLK, lay.JB
+        o = 0
+        gmu = _unpack_c(slab[o:o + NBLK * 256], NBLK, 1)[:M, :Do]
+        o += NBLK * 256
+        gs2 = _unpack_c(slab[o:o + NBLK * 256], NBLK, 1)[:M, :Do]
+        o += NBLK * 256
+        gB = _unpack_c(slab[o:o + NBLK * NBLK * 256], NBLK, NBLK)[:M, :M]
+        o += NBLK * NBLK * 256
+        gZf = _unpack_c(slab[o:o + NBLK * JB * 256], NBLK, JB)
+        o += NBLK * JB * 256
+        small = slab[o:o + 128]
+        Kinv, Kmm = pack.Kinv, pack.Kmm
+        Zs = pack.section('Zs', (M, D))
+        gZt = gZf[:M, :D] - Zs * gZf[:M, D:D + 1]           # Ebar x~^T - z~ o rowsum(Ebar)
+        glx = small[32:32 + D]
+        gsig, glogsig = small[96], small[97]
+        # prior KL (gp_tf.py:163-172), weight 1 in the loss, added once (rank invariant)
+        gmu = gmu + Kinv @ zmean
+        gs2 = gs2 + 0.5 * (torch.diagonal(Kinv)[:, None] - 1.0 / zvar)
+        gB = gB + 0.5 * (torch.diag(zvar.sum(1)) + zmean @ zmean.T)
+        # K^-1 = (K_mm + jitter I)^-1 ; log det term of the KL: d/dK (0.5 Do log det K) = 0.5 Do K^-1
+        gK = -(Kinv @ gB @ Kinv) + 0.5 * Do * Kinv
+        # K = var * exp(-0.5 d2(z~))                                           (gp_tf.py:33-49)
+        gKK = gK * Kmm
+        gvar = gKK.sum() / var[0] + gsig + glogsig / var[0]
+        Wd = -0.5 * gKK
+        Ws = Wd + Wd.T
+        gZt = gZt + 2.0 * (Ws.sum(1)[:, None] * Zs - Ws @ Zs)
+        gz = gZt / ls
+        gls = -((gZt * Zs).sum(0) + glx) / ls
+        return gz, gmu, gs2, gvar, gls, small
+
+
+class TFAdam:
+    """tf.train.AdamOptimizer's update rule (TF 1.8): lr_t = lr sqrt(1-b2^t)/(1-b1^t); p -= lr_t m/(sqrt(v)+eps)."""
+
+    def __init__(self, params, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.names = list(params.keys())
+        sizes = [params[k].numel() for k in self.names]
+        dev = params[self.names[0]].device
+        self.flat = torch.cat([params[k].reshape(-1) for k in self.names]).to(torch.float64).contiguous()
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.gflat = torch.zeros_like(self.flat)
+        self.views, self.gviews = {}, {}
+        o = 0
+        for k, n in zip(self.names, sizes):
+            self.views[k] = self.flat[o:o + n].view(params[k].shape)
+            self.gviews[k] = self.gflat[o:o + n].view(params[k].shape)
+            o += n
+        self.lr, self.b1, self.b2, self.eps = float(lr), beta1, beta2, eps
+        self.t = 0
+
+    def step(self, grads):
+        for k in self.names:
+            self.gviews[k].copy_(grads[k])
+        self.t += 1
+        g = self.gflat
+        self.m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+        lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        self.flat.addcdiv_(self.m, self.v.sqrt().add_(self.eps), value=-lr_t)
+
+    def state_dict(self):
+        return {'flat': self.flat.clone(), 'm': self.m.clone(), 'v': self.v.clone(), 't': self.t, 'names': self.names}
+
+    def load_state_dict(self, sd):
+        self.flat.copy_(sd['flat'])
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+        self.t = int(sd['t'])
+
+
+class HipTrainStep:
+    """One `sess.run((model.train, model.loss))` (training/trainer.py:40): loss, gradient, Adam update."""
+
+    def __init__(self, config, params, device, dist=None):
+        self.engine = HipElboGrad(config, device, dist)
+        p = {k: _f64(params[k], device).clone() for k in PARAM_NAMES}
+        self.opt = TFAdam(p, config['learning_rate'])
+        self.params = self.opt.views
+
+    def step(self, u, y, noise, condition=True):
+        loss, grads, terms = self.engine.loss_and_grads(self.params, u, y, noise, condition)
+        self.opt.step(grads)
+        self.last_terms = terms
+        return loss
+
+
+def train_step_smoke():
+    """Used by __graft_entry__.smoke(): one tiny train step on cuda:0, gradient checked against the CPU oracle."""
+    import numpy as np
+    from cbfssm import synthetic as syn
+    from oracle import cbfssm_torch_ref as tref
+    w = syn.tiny(M=20, T=13, B=2, S=8)
+    cfg = w.model_config()
+    p = syn.perturb_params(syn.make_params(w))
+    u, y = syn.make_inputs(w)
+    noise = syn.make_noise(w)
+    eng = HipElboGrad(cfg, 'cuda:0')
+    loss, grads, _ = eng.loss_and_grads({k: torch.tensor(v, device='cuda:0') for k, v in p.items()}, u, y, noise)
+    scal, gref = tref.loss_and_grads(cfg, p, u, y, noise, True)
+    assert abs(float(loss) - scal['loss']) <= 1e-9 * abs(scal['loss'])
+    for k in PARAM_NAMES:
+        np.testing.assert_allclose(grads[k].cpu().numpy(), gref[k], rtol=1e-6, atol=1e-7 * np.abs(gref[k]).max())
+    print('smoke ok: train-step gradient matches the oracle for all 12 tensors')

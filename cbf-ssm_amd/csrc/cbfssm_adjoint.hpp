@@ -1,0 +1,585 @@
+// Reverse-mode (adjoint) time-loop kernels of the CBF-SSM ELBO: what tf.train.AdamOptimizer.minimize differentiates
+// through the two tf.while_loops (cbfssm/model/cbfssm.py:107-111,176-179,273-275), re-derived by hand.
+//
+// One workgroup owns 16 chains and walks the recurrence backwards.  Nothing of size (M,N) is ever stored: every
+// step recomputes K = k(Z, x_t) and A2 = K^-1 K from the saved trajectory (x_t or h_t), then
+//
+//   D   per-(chain, dim) adjoint of the step epilogue  ->  Fm = d loss/d fmean, Fv = d loss/d fvar      (16 x 16 each)
+//   E   A2bar = mu Fm + 2 A2 o (s2 Fv) - K o colsum(Fv)                                                  MFMA
+//       mubar += A2 Fm^T,  s2bar += (A2 o A2) Fv^T,  Kinvbar += A2bar K^T      (k-dim = the 16 chains)    MFMA
+//   F   Kbar = Kinv A2bar - A2 o colsum(Fv);  Ebar = Kbar o K                                            MFMA
+//       xbar~ = Z~^T Ebar - x~ o colsum(Ebar),  Zbar~ += Ebar x~^T                                       MFMA
+//   G   carry d loss/d x_t (or d loss/d h_t) to the next reverse step
+//
+// Parameter adjoints accumulate in VGPRs over the whole pass and leave the kernel once, as one partial slab per
+// workgroup (summed in a fixed order by reduce_partials_kernel: bitwise reproducible, no atomics).
+#pragma once
+#include "cbfssm_kernels.hpp"
+
+namespace cbfssm {
+
+struct RevPackPtrs {
+    const double* muB;   // [NBLK][4][64]   A[row m][k = d]
+    const double* s2B;
+    const double* ZT;    // [NBLK][JB][4][64]  A[row j][k = m], row D is all ones (for m < M)
+};
+
+struct RevArgs {
+    PackPtrs pk;
+    RevPackPtrs rk;
+    int N, S, T, B;
+    int dim_x, dim_u, dim_y;
+    int Do, D;
+    int recog_len, condition;
+    double k_factor;
+    double cL;             // lambda0 / S : weight of (kl_x - loglik) in the loss      (cbfssm.py:257-262)
+    double cE;             // lambda1 / S : weight of -entropy
+    const double* var_x;
+    const double* var_y;
+    const double* u;
+    const double* y;
+    const double* eps;     // fwd: (T-1,N); bwd: (2,T,N)
+    const double* hid;     // bwd: (2,T,N)
+    const double* x;       // fwd: (T,N,dim_x) saved trajectory
+    const double* y2;      // fwd: (T,N,dob)
+    const double* h_all;   // bwd: (2,T,N,dob) saved outputs of both runs
+    double* gy2;           // (T,N,dob): written by the fwd reverse, read by the bwd reverse
+    double* gpart;         // [workgroup][slab]
+    int64_t slab;          // doubles per workgroup
+};
+
+// slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
+template <int NBLK, int JB>
+struct Slab {
+    static constexpr int gMu = 0;                              // [NBLK][256]
+    static constexpr int gS2 = gMu + NBLK * 256;               // [NBLK][256]
+    static constexpr int gB = gS2 + NBLK * 256;                // [NBLK][NBLK][256]
+    static constexpr int gZ = gB + NBLK * NBLK * 256;          // [NBLK][JB][256]
+    static constexpr int small = gZ + NBLK * JB * 256;         // 128: [0,16) gvx, [16,32) gvy, [32,32+16*JB) glx, 96 gsig, 97 glogsig
+    static constexpr int total = small + 128;
+};
+
+template <int NBLK, int DK, bool BREG, int MODE>
+__global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
+{
+    constexpr int RB = 1;
+    typedef Tile<NBLK, RB, DK, BREG> TT;
+    constexpr int W = TT::W, NT = TT::NT, MP = TT::MP, KS = TT::KS;
+    constexpr int JB = (4 * DK + 1 + 15) / 16;          // 16-row blocks covering the D inputs + the ones row
+    constexpr int NG = 4 * JB;                          // 4-row groups of the input-adjoint tile
+    constexpr int GPW = (NG + W - 1) / W;               // groups per wave in phase G
+    constexpr int PD = 17;                              // padded row length of the LDS tiles
+    constexpr int AUXR = (DK * 64 + NT - 1) / NT;
+    typedef Slab<NBLK, JB> SL;
+
+    extern __shared__ double lds[];
+    double* xq = lds;                                   // [4*DK][17]
+    double* Kt = xq + 4 * DK * PD;                      // [MP][17]
+    double* A2t = Kt + MP * PD;                         // [MP][17]
+    double* Fm = A2t + MP * PD;                         // [16][17]
+    double* Fv = Fm + 16 * PD;                          // [16][17]
+    double* TS = Fv + 16 * PD;                          // [W][16][17]
+    double* part = TS + W * 16 * PD;                    // [W][max(2,JB)][4][64]
+    constexpr int PSL = (JB > 2 ? JB : 2) * 256;
+    double* red = part + W * PSL;                       // 64
+
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
+    const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
+    const int naux = D - Do;
+    const int dob = a.dim_x - a.dim_y;
+    const int c0 = blockIdx.x * 16;
+    const int c = min(c0 + nl, N - 1);
+    const bool cvalid = (c0 + nl) < N;
+    const int bq = c / S;
+    const int run = (MODE == MODE_BWD) ? int(blockIdx.y) : 0;
+    const int R = a.recog_len, P = 2 * R;
+    double* ts = TS + w * 16 * PD;
+
+    // ---- loop-invariant operands
+    TT tile;
+    tile.load_operands(a.pk, w, l);
+    double muB[4], s2B[4], ZT[JB][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        muB[s] = a.rk.muB[(w * 4 + s) * 64 + l];
+        s2B[s] = a.rk.s2B[(w * 4 + s) * 64 + l];
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) ZT[jb][s] = a.rk.ZT[((w * JB + jb) * 4 + s) * 64 + l];
+    }
+
+    // ---- accumulators of the parameter adjoints (whole pass)
+    d4 gMu = {0, 0, 0, 0}, gS2 = {0, 0, 0, 0};
+    d4 gB[NBLK], gZ[JB];
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) gB[i] = d4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < JB; ++i) gZ[i] = d4{0, 0, 0, 0};
+
+    // ---- phase D/G lane state.  Phase D lanes: (d = 4q+g, chain nl), q = w + qi*W < 4.
+    constexpr int QPW = TT::QPW;
+    double vx[QPW], vy[QPW], il[QPW];
+    double gcar[QPW];          // adjoint of the chain state arriving from the previously processed step
+    double gdir[QPW];          // direct (residual) path adjoint of this step's input state
+    double gvx[QPW], gvy[QPW];
+    double gsig = 0.0;
+    bool act[QPW];
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+        const int q = w + qi * W;
+        const int d = 4 * q + g;
+        act[qi] = (q < 4) && (d < Do);
+        const int dc = act[qi] ? d : 0;
+        vx[qi] = a.var_x[dc];
+        vy[qi] = (MODE == MODE_FWD) ? a.var_y[dc] : 0.0;
+        il[qi] = a.pk.invl[dc];
+        gcar[qi] = 0.0; gdir[qi] = 0.0; gvx[qi] = 0.0; gvy[qi] = 0.0;
+    }
+    // Phase G lanes: input row j = 4*gi + g, gi = w + k*W < NG
+    double glx[GPW];
+    double glogsig = 0.0;
+#pragma unroll
+    for (int k2 = 0; k2 < GPW; ++k2) glx[k2] = 0.0;
+
+    auto aux_load = [&](int i, int t) -> double {
+        const int ja = i >> 4, n = i & 15;
+        if (ja >= naux) return 0.0;
+        const int cc = min(c0 + n, N - 1);
+        const int b = cc / S;
+        double v;
+        if (ja < a.dim_u) v = a.u[(int64_t(b) * T + t) * a.dim_u + ja];
+        else v = a.y[(int64_t(b) * T + t) * a.dim_y + (ja - a.dim_u)];
+        return v * a.pk.invl[Do + ja];
+    };
+
+    for (int i = tid; i < 4 * DK * PD; i += NT) xq[i] = 0.0;
+    for (int i = tid; i < 16 * PD; i += NT) { Fm[i] = 0.0; Fv[i] = 0.0; }
+    __syncthreads();
+
+    const int nsteps = (MODE == MODE_FWD) ? (T - 1) : T;
+    if (MODE == MODE_FWD && nsteps > 0) {
+        // adjoint of x_{T-1}: only the log-likelihood sees it      (cbfssm.py:245-251)
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int d = 4 * (w + qi * W) + g;
+            if (act[qi] && d < a.dim_y) {
+                const double xv = a.x[(int64_t(T - 1) * N + c) * a.dim_x + d];
+                const double yv = a.y[(int64_t(bq) * T + (T - 1)) * a.dim_y + d];
+                gcar[qi] = -a.cL * (yv - xv) / vy[qi];
+            }
+        }
+    }
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int t = (MODE == MODE_FWD) ? (T - 2 - step) : step;
+
+        // ---- A: GP input of step t from the saved trajectory
+        double hcur[QPW];
+        bool resample_t = false;
+        if (MODE == MODE_BWD) resample_t = (((t + 1 + run * R) % P) == 0);                    // cbfssm.py:124,127
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int q = w + qi * W;
+            const int d = 4 * q + g;
+            hcur[qi] = 0.0;
+            if (act[qi]) {
+                double v;
+                if (MODE == MODE_FWD) v = a.x[(int64_t(t) * N + c) * a.dim_x + d];
+                else if (resample_t) v = a.hid[(int64_t(run) * T + t) * N + c];
+                else if (t == T - 1) v = 0.0;                                                  // cbfssm.py:106
+                else v = a.h_all[((int64_t(run) * T + (t + 1)) * N + c) * Do + d];             // h_t = out_{t+1}
+                hcur[qi] = v;
+                xq[d * PD + nl] = v * il[qi];
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < AUXR; ++k2) {
+            const int i = tid + k2 * NT;
+            if (i < 16 * naux) xq[(Do + (i >> 4)) * PD + (i & 15)] = aux_load(i, t);
+        }
+        // epilogue inputs
+        double eps_t, ytil[QPW], gy2in[QPW];
+        if (MODE == MODE_FWD) {
+            eps_t = a.eps[int64_t(t) * N + c];
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int d = 4 * (w + qi * W) + g;
+                ytil[qi] = 0.0;
+                if (act[qi])
+                    ytil[qi] = (d < a.dim_y) ? a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d]
+                                             : a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)];
+            }
+        } else {
+            eps_t = a.eps[(int64_t(run) * T + t) * N + c];
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int d = 4 * (w + qi * W) + g;
+                gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
+            }
+        }
+        __syncthreads();
+
+        // ---- B: kernel tile (rows of this wave)
+        double bx[DK], xx = 0.0;
+#pragma unroll
+        for (int s = 0; s < DK; ++s) {
+            bx[s] = xq[(4 * s + g) * PD + nl];
+            xx = fma(bx[s], bx[s], xx);
+        }
+        xx += __shfl_xor(xx, 16);
+        xx += __shfl_xor(xx, 32);
+        d4 kreg;
+        {
+            d4 e;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = tile.czr[0][r] - 0.5 * xx;
+#pragma unroll
+            for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[0][s], bx[s], e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                kreg[r] = exp(e[r]);
+                Kt[(16 * w + 4 * r + g) * PD + nl] = kreg[r];
+            }
+        }
+        __syncthreads();
+
+        // ---- C: A2 rows of this wave, P1/P2
+        d4 a2;
+        {
+            d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            if constexpr (BREG) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double b = Kt[(4 * s + g) * PD + nl];
+                    if (s & 1) acc1 = CBF_MFMA(tile.Breg[0][s], b, acc1);
+                    else acc0 = CBF_MFMA(tile.Breg[0][s], b, acc0);
+                }
+            } else {
+#pragma unroll 1
+                for (int s0 = 0; s0 < KS; s0 += 4) {
+                    double b[4], aop[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        b[j] = Kt[(4 * (s0 + j) + g) * PD + nl];
+                        aop[j] = tile.Bp[(w * KS + s0 + j) * 64 + l];
+                    }
+                    acc0 = CBF_MFMA(aop[0], b[0], acc0);
+                    acc1 = CBF_MFMA(aop[1], b[1], acc1);
+                    acc0 = CBF_MFMA(aop[2], b[2], acc0);
+                    acc1 = CBF_MFMA(aop[3], b[3], acc1);
+                }
+            }
+            a2 = acc0 + acc1;
+        }
+        {
+            d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
+            double q = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                P1 = CBF_MFMA(tile.muA[0][r], a2[r], P1);
+                P2 = CBF_MFMA(tile.s2A[0][r], a2[r] * a2[r], P2);
+                q = fma(kreg[r], a2[r], q);
+            }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                part[w * PSL + (0 * 4 + r) * 64 + l] = P1[r];
+                part[w * PSL + (1 * 4 + r) * 64 + l] = P2[r] - q;
+            }
+        }
+        __syncthreads();
+
+        // ---- D: adjoint of the step epilogue
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int q = w + qi * W;
+            if (q < 4) {
+                const int d = 4 * q + g;
+                double fm = 0.0, fv = tile.sigma2;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) {
+                    fm += part[ww * PSL + (0 * 4 + q) * 64 + l];
+                    fv += part[ww * PSL + (1 * 4 + q) * 64 + l];
+                }
+                double gfm = 0.0, gfv = 0.0;
+                if (act[qi] && cvalid) {
+                    const double fmean = fm + hcur[qi];
+                    const double fvar = fv + vx[qi];
+                    const double gout = gcar[qi];
+                    if (MODE == MODE_FWD) {
+                        const bool do_cond = a.condition || (t < R - 1);                       // cbfssm.py:227
+                        if (do_cond) {
+                            const double kf1 = a.k_factor - 1.0;
+                            const double vyt = vy[qi] + kf1 * fvar;
+                            const double s = vyt + fvar;
+                            const double rs = 1.0 / s;
+                            const double k = fvar * rs;
+                            const double ydiff = ytil[qi] - fmean;
+                            const double mu = fmean + k * ydiff;
+                            const double omk = 1.0 - k;
+                            const double sig = omk * omk * fvar + k * k * vyt;
+                            const double rf = 1.0 / fvar, rsig = 1.0 / sig;
+                            const double dm = mu - fmean;
+                            // x' = mu + eps sqrt(sig);  kl = .5[log fvar - log sig + (sig + dm^2)/fvar - 1]
+                            const double gmu = gout + a.cL * dm * rf;
+                            const double gsg = gout * eps_t * 0.5 * sqrt(rsig) + a.cL * 0.5 * (rf - rsig);
+                            gfm = -a.cL * dm * rf;
+                            gfv = a.cL * 0.5 * (rf - (sig + dm * dm) * rf * rf);
+                            // mu = fmean + k (ytil - fmean)
+                            gfm += gmu * omk;
+                            double gk = gmu * ydiff;
+                            const double gyt = gmu * k;
+                            // sig = (1-k)^2 fvar + k^2 vyt
+                            gk += gsg * (-2.0 * omk * fvar + 2.0 * k * vyt);
+                            gfv += gsg * omk * omk;
+                            double gvyt = gsg * k * k;
+                            // k = fvar / s ; s = vyt + fvar ; vyt = vy + (kf-1) fvar
+                            gfv += gk * rs;
+                            const double gs = -gk * k * rs;
+                            gvyt += gs;
+                            gfv += gs;
+                            gvy[qi] += gvyt;
+                            gfv += kf1 * gvyt;
+                            if (d >= a.dim_y) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = gyt;
+                        } else {
+                            // x' = fmean + eps sqrt(fvar), no KL term                           (cbfssm.py:224,234)
+                            gfm = gout;
+                            gfv = gout * eps_t * 0.5 / sqrt(fvar);
+                            if (d >= a.dim_y) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
+                        }
+                    } else {
+                        // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
+                        const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
+                        const double gtot = gout + (write ? gy2in[qi] : 0.0);
+                        gfm = gtot;
+                        gfv = gtot * eps_t * 0.5 / sqrt(fvar) - (write ? a.cE * 0.5 / fvar : 0.0);
+                    }
+                    gvx[qi] += gfv;
+                    gsig += gfv;
+                }
+                gdir[qi] = gfm;
+                if (d < 16) {
+                    Fm[d * PD + nl] = gfm;
+                    Fv[d * PD + nl] = gfv;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- E: A2bar, and the parameter adjoints that contract over the 16 chains
+        double fvsum = 0.0;
+        double fmB[4], fvB[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            fmB[s] = Fm[(4 * s + g) * PD + nl];
+            fvB[s] = Fv[(4 * s + g) * PD + nl];
+            fvsum += fvB[s];
+        }
+        fvsum += __shfl_xor(fvsum, 16);
+        fvsum += __shfl_xor(fvsum, 32);
+        d4 a2bar;
+        {
+            d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                T1 = CBF_MFMA(muB[s], fmB[s], T1);
+                T2 = CBF_MFMA(s2B[s], fvB[s], T2);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a2bar[r] = T1[r] + 2.0 * a2[r] * T2[r] - kreg[r] * fvsum;
+                A2t[(16 * w + 4 * r + g) * PD + nl] = a2bar[r];
+            }
+        }
+        // wave-private transposes through LDS: C-layout (row g+4r, col nl) -> A-operand layout (row nl, k = 4s+g)
+        double a2T[4], abT[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ts[(g + 4 * r) * PD + nl] = a2[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a2T[s] = ts[nl * PD + 4 * s + g];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ts[(g + 4 * r) * PD + nl] = a2bar[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) abT[s] = ts[nl * PD + 4 * s + g];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // B operands with the chain index as k: [n = 4s+g][col = nl]
+            const double fmT = Fm[nl * PD + 4 * s + g];
+            const double fvT = Fv[nl * PD + 4 * s + g];
+            gMu = CBF_MFMA(a2T[s], fmT, gMu);                       // mubar[m][d]  += A2[m][n] Fm[d][n]
+            gS2 = CBF_MFMA(a2T[s] * a2T[s], fvT, gS2);              // s2bar[m][d]  += A2[m][n]^2 Fv[d][n]
+        }
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double kT = Kt[(16 * cb + nl) * PD + 4 * s + g];
+                gB[cb] = CBF_MFMA(abT[s], kT, gB[cb]);              // Kinvbar[m'][m] += A2bar[m'][n] K[m][n]
+            }
+        }
+        __syncthreads();
+
+        // ---- F: Kbar, Ebar, input adjoint partials, Zbar~
+        d4 ebar;
+        {
+            d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            if constexpr (BREG) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double b = A2t[(4 * s + g) * PD + nl];
+                    if (s & 1) acc1 = CBF_MFMA(tile.Breg[0][s], b, acc1);
+                    else acc0 = CBF_MFMA(tile.Breg[0][s], b, acc0);
+                }
+            } else {
+#pragma unroll 1
+                for (int s0 = 0; s0 < KS; s0 += 4) {
+                    double b[4], aop[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        b[j] = A2t[(4 * (s0 + j) + g) * PD + nl];
+                        aop[j] = tile.Bp[(w * KS + s0 + j) * 64 + l];
+                    }
+                    acc0 = CBF_MFMA(aop[0], b[0], acc0);
+                    acc1 = CBF_MFMA(aop[1], b[1], acc1);
+                    acc0 = CBF_MFMA(aop[2], b[2], acc0);
+                    acc1 = CBF_MFMA(aop[3], b[3], acc1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ebar[r] = (acc0[r] + acc1[r] - a2[r] * fvsum) * kreg[r];
+        }
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) {
+            d4 xp = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xp = CBF_MFMA(ZT[jb][r], ebar[r], xp);   // rows j, k = m of this wave
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[r];
+        }
+        double ebT[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ts[(g + 4 * r) * PD + nl] = ebar[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ebT[s] = ts[nl * PD + 4 * s + g];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) {
+            const int j = 16 * jb + nl;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double xT = (j < 4 * DK) ? xq[j * PD + 4 * s + g] : 0.0;
+                if (j == D) xT = 1.0;                                             // ones column: row sums of Ebar
+                gZ[jb] = CBF_MFMA(ebT[s], xT, gZ[jb]);                            // Zbar~[m][j] += Ebar[m][n] x~[j][n]
+            }
+        }
+        __syncthreads();
+
+        // ---- G: input adjoint, carried to the next reverse step
+        double esum = 0.0;   // colsum of Ebar for this lane's chain = row D of the xbar tile
+        {
+            const int jbD = D >> 4, qD = (D >> 2) & 3, gD = D & 3;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) esum += part[ww * PSL + (jbD * 4 + qD) * 64 + gD * 16 + nl];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < GPW; ++k2) {
+            const int gi = w + k2 * W;
+            if (gi < NG) {
+                const int jb = gi >> 2, q = gi & 3;
+                const int j = 16 * jb + 4 * q + g;
+                double xb = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) xb += part[ww * PSL + (jb * 4 + q) * 64 + l];
+                if (j < D && cvalid) {
+                    const double xt = xq[j * PD + nl];
+                    xb -= xt * esum;
+                    glx[k2] += xb * xt;                                            // lengthscale adjoint (inputs)
+                }
+                if (j == D && cvalid) glogsig += xb;
+                // state rows hand their adjoint to the phase-D lanes of the same (d, chain): identical lanes when
+                // jb == 0 and this wave owns group q in both phases (gi = q for gi < 4)
+                if (jb == 0) {
+#pragma unroll
+                    for (int qi = 0; qi < QPW; ++qi) {
+                        if (w + qi * W == q) {
+                            double gin = 0.0;
+                            if (act[qi] && cvalid) gin = gdir[qi] + xb * il[qi];
+                            if (MODE == MODE_FWD) {
+                                // gin = d loss/d x_t ; add the log-likelihood's own term for x_t (t >= 1)
+                                const int d = 4 * q + g;
+                                if (act[qi] && cvalid) {
+                                    if (t >= 1 && d < a.dim_y) {
+                                        const double yv = a.y[(int64_t(bq) * T + t) * a.dim_y + d];
+                                        gin += -a.cL * (yv - hcur[qi]) / vy[qi];
+                                    }
+                                    if (t == 0 && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = gin;   // x_0 = y_tilde_0
+                                }
+                                gcar[qi] = gin;
+                            } else {
+                                gcar[qi] = resample_t ? 0.0 : gin;                 // h_t = out_{t+1} unless resampled
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // (the barrier at the top of the next step orders the part/xq reads above against the next writes)
+        __syncthreads();
+    }
+
+    if (MODE == MODE_FWD && nsteps == 0) {
+        // T == 1: x_0 = y_tilde_0 only feeds the log-likelihood through its observed dims -> no gradient to y2
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int d = 4 * (w + qi * W) + g;
+            if (act[qi] && cvalid && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = 0.0;
+        }
+    }
+
+    // ---- write this workgroup's slab
+    double* slab = a.gpart + (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * a.slab;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        slab[SL::gMu + w * 256 + r * 64 + l] = gMu[r];
+        slab[SL::gS2 + w * 256 + r * 64 + l] = gS2[r];
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb) slab[SL::gB + (w * NBLK + cb) * 256 + r * 64 + l] = gB[cb][r];
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) slab[SL::gZ + (w * JB + jb) * 256 + r * 64 + l] = gZ[jb][r];
+    }
+    // small per-dimension sums: reduce over the 16 chains of each 16-lane group, lane nl == 0 writes
+    for (int i = tid; i < 128; i += NT) slab[SL::small + i] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+        const int q = w + qi * W;
+        double v1 = gvx[qi], v2 = gvy[qi];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { v1 += __shfl_xor(v1, o); v2 += __shfl_xor(v2, o); }
+        if (q < 4 && nl == 0) {
+            slab[SL::small + 4 * q + g] = v1;
+            slab[SL::small + 16 + 4 * q + g] = v2;
+        }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < GPW; ++k2) {
+        const int gi = w + k2 * W;
+        double v = glx[k2];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (gi < NG && nl == 0) slab[SL::small + 32 + 4 * gi + g] = v;
+    }
+    const double s1 = block_sum(gsig, red, tid, NT);
+    const double s2 = block_sum(glogsig, red, tid, NT);
+    if (tid == 0) {
+        slab[SL::small + 96] = s1;
+        slab[SL::small + 97] = s2;
+    }
+}
+
+}  // namespace cbfssm

@@ -7,8 +7,10 @@
 #include <cstdarg>
 #include "../../include/cbfssm_hip.h"
 #include "cbfssm_inst.hpp"
+#include "cbfssm_adjoint_inst.hpp"
 
 CBF_FOR_EACH_NBLK(CBF_DECLARE)
+CBF_FOR_EACH_REV_NBLK(CBF_REV_DECLARE)
 
 namespace cbfssm {
 
@@ -58,6 +60,10 @@ struct PrepArgs {
     double* s2A;
     double* invl;
     double* scal;
+    double* muB;
+    double* s2B;
+    double* ZT;
+    int JB;
     double* info_out;      // kmm_chol: 1 double
 };
 
@@ -164,6 +170,21 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs a)
         a.s2A[i] = ok ? a.zvar[m * Do + d] : 0.0;
     }
     for (int j = tid; j < 4 * DK; j += PREP_NT) a.invl[j] = (j < D) ? 1.0 / a.ls[j] : 0.0;
+    // adjoint-kernel images
+    for (int i = tid; i < NBLK * 4 * 64; i += PREP_NT) {
+        const int l = i & 63, s = (i >> 6) & 3, rb = i >> 8;
+        const int m = 16 * rb + (l & 15), d = 4 * s + (l >> 4);
+        const bool ok = (m < M) && (d < Do);
+        a.muB[i] = ok ? a.zmean[m * Do + d] : 0.0;
+        a.s2B[i] = ok ? a.zvar[m * Do + d] : 0.0;
+    }
+    for (int i = tid; i < NBLK * a.JB * 4 * 64; i += PREP_NT) {
+        const int l = i & 63, s = (i >> 6) & 3, jb = (i >> 8) % a.JB, rb = (i >> 8) / a.JB;
+        const int j = 16 * jb + (l & 15), m = 16 * rb + 4 * s + (l >> 4);
+        double v = 0.0;
+        if (m < M) v = (j < D) ? a.Zs[m * D + j] : ((j == D) ? 1.0 : 0.0);
+        a.ZT[i] = v;
+    }
 
     // ---- prior KL: 0.5 sum_d [ tr(K^-1 S_d) + mu_d^T K^-1 mu_d - M + log det K - log det S_d ]   (gp_tf.py:163-172)
     double acc = 0.0;
@@ -264,6 +285,17 @@ __global__ __launch_bounds__(1024) void combine_kernel(CombineArgs a)
     }
 }
 
+// Sum the per-workgroup slabs in a fixed order: out[i] = sum_wg gpart[wg][i].
+__global__ void reduce_partials_kernel(const double* gpart, int64_t slab, int nwg, double* out)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= slab) return;
+    double s = 0.0;
+    for (int k = 0; k < nwg; ++k) s += gpart[int64_t(k) * slab + i];
+    out[i] = s;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 static const int kNblk[] = {1, 2, 4, 7, 10, 13, 16, 20};
 
@@ -285,6 +317,26 @@ static int dispatch_pass(int NBLK, int DK, int mode, const PassArgs& a, dim3 gri
 #undef X
     }
     return -2;
+}
+
+static int64_t rev_slab(int NBLK, int DK)
+{
+    switch (NBLK) {
+#define X(NB) case NB: return rev_slab_nb##NB(DK);
+        CBF_FOR_EACH_REV_NBLK(X)
+#undef X
+    }
+    return 0;
+}
+
+static int dispatch_rev(int NBLK, int DK, int mode, const RevArgs& a, dim3 grid, hipStream_t st)
+{
+    switch (NBLK) {
+#define X(NB) case NB: return launch_rev_nb##NB(DK, mode, a, grid, st);
+        CBF_FOR_EACH_REV_NBLK(X)
+#undef X
+    }
+    return -3;
 }
 
 static PackPtrs pack_ptrs(const cbfssm_pack_layout* L, const double* pack)
@@ -351,6 +403,11 @@ int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out)
     out->Kinv = take(int64_t(M) * M);
     out->Linvt = take(int64_t(M) * M);
     out->Zs = take(int64_t(M) * D);
+    out->JB = (4 * dk + 1 + 15) / 16;
+    out->muB = take(int64_t(nblk) * 256);
+    out->s2B = take(int64_t(nblk) * 256);
+    out->ZT = take(int64_t(nblk) * out->JB * 256);
+    out->rev_slab = rev_slab(nblk, dk);
     out->total = o;
     return 0;
 }
@@ -381,6 +438,7 @@ int cbfssm_gp_prepare_f64(const cbfssm_pack_layout* L, const double* Z, const do
     a.Kmm = pack + L->Kmm; a.A = pack + L->L; a.G = pack + L->Linvt; a.C = pack + L->Kinv; a.Zs = pack + L->Zs;
     a.Bp = pack + L->Bp; a.Zp = pack + L->Zp; a.cz = pack + L->cz; a.muA = pack + L->muA; a.s2A = pack + L->s2A;
     a.invl = pack + L->invl; a.scal = pack + L->scal;
+    a.muB = pack + L->muB; a.s2B = pack + L->s2B; a.ZT = pack + L->ZT; a.JB = L->JB;
     hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(PREP_NT), 0, (hipStream_t)stream, a);
     return check_launch("gp_prepare");
 }
@@ -489,6 +547,75 @@ int cbfssm_elbo_combine_f64(const cbfssm_problem* p, double lambda0, double lamb
     a.out = out;
     hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
     return check_launch("elbo_combine");
+}
+
+int64_t cbfssm_rev_workgroups(const cbfssm_problem* p, int backward_runs)
+{
+    if (!p) return -1;
+    return (int64_t(p->B) * p->S + 15) / 16 * (backward_runs ? 2 : 1);
+}
+
+static int fill_rev(RevArgs& a, const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack, int Do)
+{
+    memset(&a, 0, sizeof(a));
+    a.pk = pack_ptrs(L, pack);
+    a.rk.muB = pack + L->muB; a.rk.s2B = pack + L->s2B; a.rk.ZT = pack + L->ZT;
+    a.N = p->B * p->S; a.S = p->S; a.T = p->T; a.B = p->B;
+    a.dim_x = p->dim_x; a.dim_u = p->dim_u; a.dim_y = p->dim_y; a.Do = Do; a.D = L->D;
+    a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = p->k_factor;
+    a.slab = L->rev_slab;
+    if (L->rev_slab <= 0)
+        return fail(-3, "no adjoint kernel for M=%d (tile height %d): training supports M <= 112 in this build",
+                    L->M, L->NBLK);
+    return 0;
+}
+
+int cbfssm_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                                const double* var_x, const double* var_y, const double* u, const double* y,
+                                const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
+                                double* gpart, void* stream)
+{
+    int rc = check_problem(p, L, p ? p->dim_x : 0);
+    if (rc) return rc;
+    if (!pack_f || !var_x || !var_y || !u || !y || !x || !gpart) return fail(-1, "null pointer");
+    if (p->dim_x > p->dim_y && (!y2 || !gy2)) return fail(-1, "y2/gy2 is null");
+    if (p->T > 1 && !eps_f) return fail(-1, "eps_f is null");
+    RevArgs a;
+    rc = fill_rev(a, p, L, pack_f, p->dim_x);
+    if (rc) return rc;
+    a.cL = cL; a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.x = x; a.y2 = y2; a.gy2 = gy2;
+    a.gpart = gpart;
+    dim3 grid(unsigned((a.N + 15) / 16), 1);
+    rc = dispatch_rev(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
+    if (rc) return fail(rc, "forward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
+    return 0;
+}
+
+int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_b,
+                                 const double* var_x, const double* u, const double* y, const double* hid_b,
+                                 const double* eps_b, const double* h_all, const double* gy2, double cE,
+                                 double* gpart, void* stream)
+{
+    int rc = check_problem(p, L, p ? p->dim_x - p->dim_y : 0);
+    if (rc) return rc;
+    if (!pack_b || !var_x || !u || !y || !hid_b || !eps_b || !h_all || !gy2 || !gpart) return fail(-1, "null pointer");
+    RevArgs a;
+    rc = fill_rev(a, p, L, pack_b, p->dim_x - p->dim_y);
+    if (rc) return rc;
+    a.cE = cE; a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.h_all = h_all;
+    a.gy2 = const_cast<double*>(gy2); a.gpart = gpart;
+    dim3 grid(unsigned((a.N + 15) / 16), 2);
+    rc = dispatch_rev(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
+    if (rc) return fail(rc, "backward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
+    return 0;
+}
+
+int cbfssm_reduce_partials_f64(const double* gpart, int64_t slab, int64_t nwg, double* out, void* stream)
+{
+    if (!gpart || !out || slab < 1 || nwg < 1 || nwg > (1 << 30)) return fail(-1, "bad reduce arguments");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(unsigned((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       gpart, slab, int(nwg), out);
+    return check_launch("reduce_partials");
 }
 
 }  // extern "C"

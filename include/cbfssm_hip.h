@@ -52,7 +52,11 @@ typedef struct {
     int64_t Kinv;     /* [M][M]          (K_mm + jitter I)^-1                                                */
     int64_t Linvt;    /* [M][M]          L^-T (upper triangular), by-product of the factorisation            */
     int64_t Zs;       /* [M][D]          Z / lengthscale                                                     */
-    int32_t M, D, Do, NBLK, DK, Mp, Dp, KS;
+    int64_t muB;      /* [NBLK][4][64]   zeta_mean as A-operand image A[row m][k = d]      (adjoint kernels)        */
+    int64_t s2B;      /* [NBLK][4][64]   zeta_var, same image                                                        */
+    int64_t ZT;       /* [NBLK][JB][4][64] (Z/lengthscale)^T as A-operand image A[row j][k = m]; row D = ones        */
+    int64_t rev_slab; /* doubles of one adjoint partial slab (0: no adjoint kernel for this tile height)            */
+    int32_t M, D, Do, NBLK, DK, Mp, Dp, KS, JB, pad_;
 } cbfssm_pack_layout;
 
 /* Problem description shared by the pass kernels (host struct, passed by pointer). */
@@ -142,6 +146,45 @@ int cbfssm_elbo_combine_f64(const cbfssm_problem* p, double lambda0, double lamb
                             const double* ll_part, int64_t n_ll, const double* kl_part, int64_t n_kl,
                             const double* ent_part, int64_t n_ent, const double* scal_f, const double* scal_b,
                             double* out, void* stream);
+
+/*
+ * ---- adjoint (reverse-mode) entry points: what tf.train.AdamOptimizer.minimize differentiates (cbfssm.py:273-275).
+ *
+ * Slab layout of the parameter adjoints of one GP (layout->rev_slab doubles; C = MFMA accumulator layout,
+ * element [blk][r][lane] -> row 16*blk_row + (lane>>4) + 4r, col 16*blk_col + (lane&15)):
+ *   [0, NBLK*256)                       d loss / d zeta_mean   (Mp x 16)
+ *   [NBLK*256, 2*NBLK*256)              d loss / d zeta_var    (Mp x 16)
+ *   then NBLK*NBLK*256                  d loss / d K^-1        (Mp x Mp), data terms only
+ *   then NBLK*JB*256                    d loss / d (Z/ls)      (Mp x 16*JB): column D holds the row sums of Ebar,
+ *                                       the caller subtracts (Z/ls) o rowsum
+ *   then 128 scalars: [0,16) d/d var_x (by state dim), [16,32) d/d var_y, [32,32+16*JB) sum_n xbar~ x~ by input
+ *                     row (lengthscale adjoint of the inputs), [96] d/d sigma^2 (direct), [97] d/d log sigma^2
+ */
+int64_t cbfssm_rev_workgroups(const cbfssm_problem* p, int backward_runs);
+
+/*
+ * Adjoint of cbfssm_forward_pass_f64 (reverse of the tf.while_loop in CBFSSM._forward, cbfssm.py:176-237) including
+ * the log-likelihood's pull on x (cbfssm.py:245-251).
+ *   x, y2, eps_f as saved by the forward evaluation; cL = loss_factors[0]/S.
+ *   -> gy2 (T,N,dim_x-dim_y): d loss / d y2 ; gpart: cbfssm_rev_workgroups(p,0) slabs of layout_f->rev_slab doubles.
+ */
+int cbfssm_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
+                                const double* var_x, const double* var_y, const double* u, const double* y,
+                                const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
+                                double* gpart, void* stream);
+
+/*
+ * Adjoint of cbfssm_backward_pass_f64 (both runs; reverse of the tf.while_loops in CBFSSM._backward_run,
+ * cbfssm.py:107-158).  h_all as saved by the forward evaluation, gy2 from cbfssm_forward_pass_bwd_f64,
+ * cE = loss_factors[1]/S.  -> gpart: cbfssm_rev_workgroups(p,1) slabs of layout_b->rev_slab doubles.
+ */
+int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const double* pack_b,
+                                 const double* var_x, const double* u, const double* y, const double* hid_b,
+                                 const double* eps_b, const double* h_all, const double* gy2, double cE,
+                                 double* gpart, void* stream);
+
+/* out[i] = sum over the nwg slabs, in slab order (bitwise reproducible). */
+int cbfssm_reduce_partials_f64(const double* gpart, int64_t slab, int64_t nwg, double* out, void* stream);
 
 #ifdef __cplusplus
 }
