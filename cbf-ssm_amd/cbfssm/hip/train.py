@@ -17,6 +17,7 @@ import torch
 from . import lib as _l
 from . import ops
 from .ops import _ptr, _stream, _f64, tf_forward, GPPack
+from .dist_utils import all_reduce_sum
 
 PARAM_NAMES = (
     'f.zeta_pos', 'f.zeta_mean', 'f.zeta_var_unc', 'f.variance_unc', 'f.lengthscales_unc',
@@ -34,7 +35,7 @@ def _unpack_c(v, nrb, ncb):
 class HipElboGrad:
     """loss and d loss / d (12 unconstrained tensors) for one mini-batch on one device."""
 
-    def __init__(self, config, device, dist=None):
+    def __init__(self, config, device, dist=None, require_adjoint=True):
         self.config = config
         self.device = torch.device(device)
         self.dist = dist
@@ -44,16 +45,22 @@ class HipElboGrad:
         self.dob = self.dim_x - self.dim_y
         self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device)
         self.pack_b = GPPack(self.M, self.D, self.dob, self.device)
-        for pk in (self.pack_f, self.pack_b):
-            if pk.layout.rev_slab <= 0:
-                raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d): training supports M <= 112 in '
-                                        'this build' % (self.M, pk.layout.NBLK))
-        self.slab_f = int(self.pack_f.layout.rev_slab)
-        self.slab_b = int(self.pack_b.layout.rev_slab)
+        self.has_adjoint = all(pk.layout.rev_slab > 0 for pk in (self.pack_f, self.pack_b))
+        if require_adjoint:
+            self._need_adjoint()
+        self.slab_f = max(0, int(self.pack_f.layout.rev_slab))
+        self.slab_b = max(0, int(self.pack_b.layout.rev_slab))
+        self.last_ws = None
         # flat reduce buffer: [slab_f | slab_b | loglik, kl_x, entropy, gvy_ll[dim_y]]
         self.nred = self.slab_f + self.slab_b + 3 + self.dim_y
         self.red = torch.zeros(self.nred, dtype=torch.float64, device=self.device)
         self._ws = {}
+
+    def _need_adjoint(self):
+        if not self.has_adjoint:
+            raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d): training supports M <= 112 in this '
+                                    'build; evaluation works for every M <= 320'
+                                    % (self.M, self.pack_f.layout.NBLK))
 
     # ---- forward evaluation (keeps what the adjoint needs)
     def _constrained(self, p):
@@ -65,6 +72,42 @@ class HipElboGrad:
         c['var_x'] = tf_forward(p['var_x_unc']).contiguous()
         c['var_y'] = tf_forward(p['var_y_unc']).contiguous()
         return c
+
+    def forward(self, params, u, y, noise, condition=True):
+        """Loss only (what Trainer's test pass and Outputs fetch): returns (loss 0-d tensor, terms, workspace)."""
+        dev = self.device
+        cfg = self.config
+        p = {k: _f64(params[k], dev) for k in PARAM_NAMES}
+        u, y = _f64(u, dev), _f64(y, dev)
+        B, T = u.shape[0], u.shape[1]
+        prob = _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, cfg['recog_len'],
+                               cfg['k_factor'], condition)
+        c = self._constrained(p)
+        self.pack_f.prepare(p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar'])
+        self.pack_b.prepare(p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar'])
+        key = ('eval', B, T)
+        if key not in self._ws:
+            self._ws[key] = ops.ElboWorkspace(prob, dev, keep_h=False)
+        ws = self._ws[key]
+        hid_b, eps_b, eps_f = (_f64(noise[k], dev) for k in ('hid_b', 'eps_b', 'eps_f'))
+        ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f,
+                         cfg['loss_factors'], ws)
+        out = ws.out
+        if self.dist is not None:
+            # data terms summed over the ranks' shards, prior KL counted once (cbfssm.py:257-261)
+            red = out[0:3].clone()
+            all_reduce_sum(red, self.dist)
+            lf = cfg['loss_factors']
+            cL, cE = float(lf[0]) / self.S, float(lf[1]) / self.S
+            loss = -(red[0] * cL - red[1] * cL + red[2] * cE - out[3] - out[4])
+            terms = {'loglik': red[0], 'kl_x': red[1], 'entropy': red[2], 'kl_z_f': out[3], 'kl_z_b': out[4],
+                     'info': out[7]}
+        else:
+            loss = out[6]
+            terms = {'loglik': out[0], 'kl_x': out[1], 'entropy': out[2], 'kl_z_f': out[3], 'kl_z_b': out[4],
+                     'info': out[7]}
+        self.last_ws = ws
+        return loss, terms, ws
 
     def _workspace(self, prob):
         key = (prob.B, prob.T)
@@ -83,6 +126,7 @@ class HipElboGrad:
 
     def loss_and_grads(self, params, u, y, noise, condition=True):
         """params: dict of unconstrained float64 device tensors.  Returns (loss 0-d tensor, grads dict, terms)."""
+        self._need_adjoint()
         lib = _l.load()
         dev = self.device
         cfg = self.config
@@ -95,6 +139,7 @@ class HipElboGrad:
         self.pack_f.prepare(p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar'])
         self.pack_b.prepare(p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar'])
         ws = self._workspace(prob)
+        self.last_ws = ws
         hid_b, eps_b, eps_f = (_f64(noise[k], dev) for k in ('hid_b', 'eps_b', 'eps_f'))
         lf = cfg['loss_factors']
         ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws)
@@ -126,7 +171,7 @@ class HipElboGrad:
         tail[0:3] = ws.out[0:3]
         tail[3:] = gvy_ll
         if self.dist is not None:
-            self.dist.all_reduce(red)          # the one collective of a train step (RCCL over xGMI)
+            all_reduce_sum(red, self.dist)     # the one collective of a train step (RCCL over xGMI)
 
         # ---- once-per-step adjoints and the chain through the positivity transforms
         grads = {}

@@ -1,0 +1,189 @@
+"""cbfssm.model.CBFSSM on the MI355X HIP path: the attribute surface the reference's callers use
+(cbfssm/model/cbfssm.py:10-277 as consumed by training/trainer.py:18-63 and outputs/outputs.py:36-164):
+
+    CBFSSM(config)            config dict of run/template.py:19-40; config['ds'] is a class with dim_u/dim_y
+    .graph .init .saver .condition .train .loss .pred_mean .pred_var .internal_mean .internal_var .mse .sde .var_dict
+    .load_ds(sess, in, out)   .run(sess, tensors, feed_dict)
+
+One `sess.run` evaluates one mini-batch: noise is drawn on the device (one normal per (b, s) and step, tiled over the
+state dimensions, cbfssm.py:134,149,209), the ELBO and -- when `train` is fetched -- its gradient and the Adam update
+run in the hand-written kernels behind include/cbfssm_hip.h.  There is no CPU path.
+"""
+import os
+import numpy as np
+import torch
+
+from .base_model import BaseModel
+from .session import Fetch, Saver, InvalidArgumentError
+from ..synthetic import softplus_inverse
+
+_FETCHES = ('train', 'loss', 'pred_mean', 'pred_var', 'internal_mean', 'internal_var', 'mse', 'sde',
+            'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b', 'x_final', 'y_tilde')
+
+
+def backward(y):
+    """inverse softplus of the positive initial values (cbfssm/model/tf_transform.py:13-16)."""
+    return softplus_inverse(y)
+
+
+class CBFSSM(BaseModel):
+
+    def __init__(self, config, dtype='float64'):
+        if str(dtype) not in ('float64', 'torch.float64', "<dtype: 'float64'>"):
+            raise NotImplementedError('the HIP path computes in float64 (the reference default, cbfssm.py:12)')
+        super(CBFSSM, self).__init__(config, dtype='float64')
+
+    # ---- cbfssm.py:15-23
+    def _build_graph(self):
+        self._setup_vars()
+        for name in _FETCHES:
+            setattr(self, name, Fetch(self, name))
+        self.init = Fetch(self, 'init')
+        self.saver = Saver(self)
+        self._engine = None
+        self._opt = None
+        self._device = None
+        self._gen = None
+        self._dist = None
+
+    # ---- cbfssm.py:25-67 (numpy initial values; unseeded unless config['seed'] is given)
+    def _setup_vars(self):
+        c = self.config
+        self.dim_u, self.dim_y, self.dim_x = c['ds'].dim_u, c['ds'].dim_y, c['dim_x']
+        M, D = c['ind_pnt_num'], self.dim_x + self.dim_u
+        rng = self._rng
+        init = {}
+        for g, dout in (('f', self.dim_x), ('b', self.dim_x - self.dim_y)):
+            init[g + '.zeta_pos'] = rng.uniform(-c['zeta_pos'], c['zeta_pos'], size=(M, D))          # gp_tf.py:112-115
+            init[g + '.zeta_mean'] = c['zeta_mean'] * rng.random((M, dout))                           # gp_tf.py:117-118
+            init[g + '.zeta_var_unc'] = backward(c['zeta_var'] * np.ones((M, dout)))                  # gp_tf.py:120-121
+            init[g + '.variance_unc'] = backward(c['gp_var'])                                         # gp_tf.py:25-26
+            init[g + '.lengthscales_unc'] = backward(np.asarray([c['gp_len']] * D, dtype=np.float64))  # gp_tf.py:29-30
+        init['var_x_unc'] = backward(c['var_x'])                                                      # cbfssm.py:51
+        init['var_y_unc'] = backward(c['var_y'])                                                      # cbfssm.py:53
+        self._init_values = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in init.items()}
+        names = {'process noise': ('var_x_unc', True), 'observation noise': ('var_y_unc', True)}
+        for g in 'fb':
+            names['kernel lengthscales ' + g] = (g + '.lengthscales_unc', True)
+            names['kernel variance ' + g] = (g + '.variance_unc', True)
+            names['IP pos ' + g] = (g + '.zeta_pos', False)
+            names['IP mean ' + g] = (g + '.zeta_mean', False)
+            names['IP var ' + g] = (g + '.zeta_var_unc', True)
+        self._var_spec = names
+        self.var_dict = {k: Fetch(self, 'var:' + k) for k in names}                                   # cbfssm.py:56-67
+
+    # ---- engine plumbing
+    def _ensure(self, sess):
+        if self._engine is not None:
+            return
+        from ..hip.train import HipElboGrad, TFAdam, PARAM_NAMES
+        dist = None
+        try:
+            import torch.distributed as td
+            if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+                dist = td
+        except ImportError:
+            pass
+        self._dist = dist
+        self._device = sess.device
+        self._engine = HipElboGrad(self.config, sess.device, dist, require_adjoint=False)
+        params = {k: torch.tensor(self._init_values[k], device=sess.device) for k in PARAM_NAMES}
+        self._opt = TFAdam(params, self.config['learning_rate'])                                      # cbfssm.py:274
+        self._gen = torch.Generator(device=sess.device)
+        seed = self.config.get('seed', None)
+        seed = int(seed) if seed is not None else int.from_bytes(os.urandom(4), 'little')
+        if dist is not None:
+            # data parallel: same iteration order on every rank, each rank takes its shard of every mini-batch
+            from ..hip.dist_utils import broadcast_seed
+            seed = broadcast_seed(seed, dist)
+            self._rng = np.random.default_rng(seed)
+            self._rank, self._world = dist.get_rank(), dist.get_world_size()
+            self._gen.manual_seed(seed + 7919 * (self._rank + 1))
+        else:
+            self._gen.manual_seed(seed)
+
+    def _state_dict(self):
+        sd = self._opt.state_dict()
+        return {'flat': sd['flat'].cpu(), 'm': sd['m'].cpu(), 'v': sd['v'].cpu(), 't': int(sd['t']),
+                'names': list(sd['names'])}
+
+    def _load_state_dict(self, sess, sd):
+        self._ensure(sess)
+        assert list(sd['names']) == list(self._opt.names), 'checkpoint belongs to a different model'
+        dev = self._device
+        self._opt.load_state_dict({'flat': sd['flat'].to(dev), 'm': sd['m'].to(dev), 'v': sd['v'].to(dev), 't': sd['t']})
+
+    def _draw_noise(self, B, T):
+        S = self.config['samples']
+        N = B * S
+        buf = torch.empty(4 * T * N + (T - 1) * N, dtype=torch.float64, device=self._device)
+        buf.normal_(generator=self._gen)
+        a = 2 * T * N
+        return {'hid_b': buf[:a], 'eps_b': buf[a:2 * a], 'eps_f': buf[2 * a:]}
+
+    # ---- one sess.run
+    def _execute(self, sess, names, feed):
+        self._ensure(sess)
+        if names == ['init']:
+            for k, v in self._init_values.items():
+                self._opt.views[k].copy_(torch.tensor(v, device=self._device))
+            self._opt.m.zero_()
+            self._opt.v.zero_()
+            self._opt.t = 0
+            return [None]
+        if all(n.startswith('var:') for n in names):
+            return [self._var_value(n[4:]) for n in names]
+        if 'condition' not in feed:
+            raise KeyError('feed_dict must set model.condition (cbfssm.py:227)')
+        condition = bool(feed['condition'])
+        data_in, data_out = self._next_batch()
+        if self._dist is not None:
+            from ..hip.dist_utils import shard_range
+            lo, hi = shard_range(data_in.shape[0], self._rank, self._world)
+            if hi <= lo:
+                raise ValueError('mini-batch of %d sequences cannot be sharded over %d ranks'
+                                 % (data_in.shape[0], self._world))
+            data_in, data_out = data_in[lo:hi], data_out[lo:hi]
+        u = torch.tensor(data_in, device=self._device)
+        y = torch.tensor(data_out, device=self._device)
+        B, T = u.shape[0], u.shape[1]
+        noise = self._draw_noise(B, T)
+        eng = self._engine
+        if 'train' in names:
+            loss, grads, terms = eng.loss_and_grads(self._opt.views, u, y, noise, condition)
+            self._opt.step(grads)                                                                     # cbfssm.py:275
+            ws = eng.last_ws
+        else:
+            loss, terms, ws = eng.forward(self._opt.views, u, y, noise, condition)
+        if float(terms['info']) != 0.0:
+            raise InvalidArgumentError('Cholesky decomposition was not successful: leading minor %d of K_mm + 1e-8 I '
+                                       'is not positive definite' % int(float(terms['info'])))
+        S = self.config['samples']
+        out = []
+        for n in names:
+            if n == 'train':
+                out.append(None)
+            elif n == 'loss':
+                out.append(np.float64(float(loss)))
+            elif n in ('loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b'):
+                out.append(np.float64(float(terms[n])))
+            elif n in ('pred_mean', 'pred_var', 'internal_mean', 'internal_var'):
+                out.append(getattr(ws, {'internal_mean': 'int_mean', 'internal_var': 'int_var'}.get(n, n)).cpu().numpy())
+            elif n == 'mse':                                                                          # cbfssm.py:270
+                out.append(np.float64(float(torch.mean((ws.pred_mean - y) ** 2))))
+            elif n == 'sde':                                                                          # cbfssm.py:271
+                out.append((torch.abs(ws.pred_mean - y) / torch.sqrt(ws.pred_var)).cpu().numpy())
+            elif n == 'x_final':                                                                      # cbfssm.py:181
+                out.append(ws.x.view(T, B, S, self.dim_x).permute(1, 0, 2, 3).cpu().numpy())
+            elif n == 'y_tilde':                                                                      # cbfssm.py:95-97
+                y2 = ws.y2.view(T, B, S, self.dim_x - self.dim_y).permute(1, 0, 2, 3)
+                out.append(torch.cat((y[:, :, None, :].expand(B, T, S, self.dim_y), y2), dim=3).cpu().numpy())
+            else:
+                raise KeyError(n)
+        return out
+
+    def _var_value(self, name):
+        from ..hip.ops import tf_forward
+        key, positive = self._var_spec[name]
+        v = self._opt.views[key]
+        return (tf_forward(v) if positive else v).cpu().numpy()

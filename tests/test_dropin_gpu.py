@@ -1,0 +1,52 @@
+"""End-to-end run of the reference's run-script flow (run/template.py:50-64) against this package on the GPU:
+dataset -> model -> Trainer.train -> Outputs.create_all, then a retrain (run/run_robomove.py:47,64 curriculum)."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_template_flow(tmp_path):
+    from cbfssm.datasets import make_synthetic_ds
+    from cbfssm.training import Trainer
+    from cbfssm.outputs import Outputs, OutputSummary
+    from cbfssm.model import CBFSSM
+
+    root_dir = str(tmp_path / 'exp')
+    ds_sel = make_synthetic_ds(dim_u=1, dim_y=1, n_train=400, n_test=160, seed=1)
+    dim_x = 3
+    model_config = {
+        'ds': ds_sel, 'batch_size': 8, 'shuffle': 10000, 'seed': 5,
+        'dim_x': dim_x, 'ind_pnt_num': 20, 'samples': 10, 'learning_rate': 0.05,
+        'loss_factors': np.asarray([1., 0.]), 'k_factor': 5., 'recog_len': 8,
+        'zeta_pos': 2., 'zeta_mean': 0.05 ** 2, 'zeta_var': 0.01 ** 2,
+        'var_x': np.asarray([0.002 ** 2] * dim_x), 'var_y': np.asarray([1. ** 2] * dim_x),
+        'gp_var': 0.5 ** 2, 'gp_len': 2.,
+    }
+    summary = OutputSummary(root_dir)
+    outputs = Outputs(root_dir)
+    ds = ds_sel(40, 20)
+    outputs.set_ds(ds)
+    model = CBFSSM(model_config)
+    outputs.set_model(model, root_dir)
+    trainer = Trainer(model, root_dir)
+    trainer.train(ds, 4)
+    outputs.set_trainer(trainer)
+    outputs.create_all()
+    summary.add_outputs(outputs)
+    summary.write_summary()
+
+    assert len(trainer.train_all) == 4 and all(np.isfinite(trainer.train_all)) and all(np.isfinite(trainer.test_all))
+    assert trainer.train_all[-1] < trainer.train_all[0]
+    for f in ('best.ckpt', 'model.ckpt', 'mse.txt', 'var_dump.txt', 'predict_train.mat', 'predict_test.mat',
+              'summary.txt'):
+        assert os.path.isfile(os.path.join(root_dir, f)), f
+    assert np.isfinite(outputs.get_last_rmse())
+    text = open(os.path.join(root_dir, 'var_dump.txt')).read()
+    assert 'process noise:' in text and 'IP pos f:' in text
+
+    # resume from model.ckpt: Adam state and parameters continue (trainer.py:30-31)
+    trainer2 = Trainer(model, root_dir)
+    trainer2.train(ds, 1, retrain=True)
+    assert trainer2.train_all[0] < trainer.train_all[0]

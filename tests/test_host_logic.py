@@ -1,0 +1,107 @@
+"""CPU tests of the host-side mirror of the reference interface: iterator semantics, windowing, dataset classes,
+checkpoint-free pieces of the model surface (nothing here needs the GPU)."""
+import numpy as np
+import pytest
+
+from cbfssm.model.base_model import shuffle_order, BaseModel
+from cbfssm.model.session import OutOfRangeError
+from cbfssm.datasets import BaseDS, make_synthetic_ds, Sarcos, Actuator, RoboMove
+from cbfssm.model import CBFSSM, CBFSSMHALF
+from cbfssm import synthetic as syn
+
+
+def test_rnn_batches_windows_and_tail():
+    x = np.arange(2 * 23 * 1, dtype=float).reshape(2, 23, 1)
+    w = BaseDS.rnn_batches(x, 10, 4, 0)
+    # starts 0,4,8,12 + tail window (23-10) % 4 = 1 > 0  -> 5 windows per experiment (base_ds.py:64-74)
+    assert w.shape == (10, 10, 1)
+    assert np.array_equal(w[4, :, 0], x[0, -10:, 0])
+    w = BaseDS.rnn_batches(x[:, :22], 10, 4, 0)      # (22-10) % 4 == 0 -> no tail window
+    assert w.shape == (8, 10, 1)
+    with pytest.raises(AssertionError):
+        BaseDS.rnn_batches(x, 30, 1, 0)
+
+
+def test_shuffle_order_is_a_permutation_with_bounded_displacement():
+    rng = np.random.default_rng(0)
+    o = shuffle_order(100, 10, rng)
+    assert sorted(o.tolist()) == list(range(100))
+    # tf.data shuffle(buffer): element i cannot be emitted before position i - buffer + 1
+    assert all(pos >= e - 9 for pos, e in enumerate(o))
+    assert np.array_equal(shuffle_order(7, 1, rng), np.arange(7))
+    o = shuffle_order(50, 10000, rng)
+    assert sorted(o.tolist()) == list(range(50)) and not np.array_equal(o, np.arange(50))
+
+
+def test_iterator_keeps_partial_final_batch_and_repeats():
+    m = BaseModel({'batch_size': 4, 'shuffle': 1})
+    a = np.arange(10 * 3 * 2, dtype=float).reshape(10, 3, 2)
+    m.load_ds(None, a, a[:, :, :1])
+    sizes = []
+    while True:
+        try:
+            sizes.append(m._next_batch()[0].shape[0])
+        except OutOfRangeError:
+            break
+    assert sizes == [4, 4, 2]
+    m.load_ds(None, a, a[:, :, :1], repeats=2)
+    n = 0
+    while True:
+        try:
+            n += m._next_batch()[0].shape[0]
+        except OutOfRangeError:
+            break
+    assert n == 20
+
+
+def test_synthetic_ds_and_normalisation():
+    ds = make_synthetic_ds(dim_u=2, dim_y=3, n_train=300, n_test=100)(50, 25)
+    assert ds.train_in.shape == (1, 300, 2) and ds.test_out.shape == (1, 100, 3)
+    assert ds.train_in_batch.shape == (11, 50, 2) and ds.test_in_batch.shape == (3, 50, 2)
+    np.testing.assert_allclose(ds.train_in[0].mean(0), 0, atol=1e-12)
+    np.testing.assert_allclose(ds.train_out[0].std(0), 1, atol=1e-12)
+    back = ds.denormalize(ds.normalize(np.ones((4, 3)), 'out'), 'out')
+    np.testing.assert_allclose(back, 1.0)
+
+
+def test_file_datasets_fail_loudly_without_their_files(tmp_path, monkeypatch):
+    monkeypatch.setenv('CBFSSM_DATA_DIR', str(tmp_path))
+    for cls in (Sarcos, Actuator, RoboMove):
+        assert cls.dim_u >= 1 and cls.dim_y >= 1
+        with pytest.raises(FileNotFoundError):
+            cls(50, 10)
+
+
+def test_actuator_loader_reads_reference_format(tmp_path, monkeypatch):
+    import scipy.io
+    rng = np.random.default_rng(0)
+    scipy.io.savemat(str(tmp_path / 'actuator.mat'), {'u': rng.standard_normal((1024, 1)), 'p': rng.standard_normal((1024, 1))})
+    monkeypatch.setenv('CBFSSM_DATA_DIR', str(tmp_path))
+    ds = Actuator(50, 1)
+    assert ds.train_in.shape == (1, 512, 1) and ds.test_in.shape == (1, 512, 1)
+    assert ds.train_in_batch.shape == (463, 50, 1)
+
+
+def test_model_surface_without_gpu():
+    w = syn.tiny()
+    cfg = w.model_config()
+    cfg['seed'] = 3
+    m = CBFSSM(cfg)
+    for name in ('graph', 'init', 'saver', 'condition', 'train', 'loss', 'pred_mean', 'pred_var', 'var_dict',
+                 'load_ds', 'run'):
+        assert hasattr(m, name), name
+    assert set(m.var_dict) == {'process noise', 'observation noise', 'kernel lengthscales f', 'kernel variance f',
+                               'IP pos f', 'IP mean f', 'IP var f', 'kernel lengthscales b', 'kernel variance b',
+                               'IP pos b', 'IP mean b', 'IP var b'}
+    iv = m._init_values
+    assert iv['f.zeta_pos'].shape == (w.M, w.D) and iv['b.zeta_mean'].shape == (w.M, w.dim_x - w.dim_y)
+    assert np.all(np.abs(iv['f.zeta_pos']) <= cfg['zeta_pos'])
+    np.testing.assert_allclose(np.logaddexp(0, iv['var_x_unc']) + 1e-10, cfg['var_x'], rtol=1e-9)
+    with pytest.raises(NotImplementedError):
+        CBFSSMHALF(cfg)
+    with m.graph.as_default():
+        pass
+    bad = dict(cfg)
+    bad['var_x'] = np.zeros(w.dim_x)
+    with pytest.raises(AssertionError):
+        CBFSSM(bad)          # tf_transform.backward asserts positivity (tf_transform.py:14)
