@@ -18,13 +18,13 @@ SYMBOLS = (
     'cbfssm_gp_predict_f64', 'cbfssm_backward_pass_partials', 'cbfssm_backward_pass_f64',
     'cbfssm_forward_pass_partials', 'cbfssm_forward_pass_f64', 'cbfssm_loglik_moments_f64',
     'cbfssm_elbo_combine_f64', 'cbfssm_rev_workgroups', 'cbfssm_forward_pass_bwd_f64',
-    'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64',
+    'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64',
 )
 
 
 class PackLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('total', 'Bp', 'Zp', 'cz', 'muA', 's2A', 'invl', 'scal', 'Kmm', 'L', 'Kinv',
-                                          'Linvt', 'Zs', 'muB', 's2B', 'ZT', 'rev_slab')] + \
+                                          'Linvt', 'Zs', 'muB', 's2B', 'ZT', 'rev_slab', 'work')] + \
                [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS', 'JB', 'pad_')]
 
 
@@ -56,6 +56,7 @@ def load():
     lib.cbfssm_gp_pack_layout.argtypes = [ip, ip, ip, C.POINTER(PackLayout)]
     lib.cbfssm_kmm_chol_f64.argtypes = [ip, ip, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
     lib.cbfssm_gp_prepare_f64.argtypes = [C.POINTER(PackLayout), vp, vp, vp, vp, vp, dbl, vp, vp]
+    lib.cbfssm_gp_prepare2_f64.argtypes = ([C.POINTER(PackLayout)] + [vp] * 6) * 2 + [dbl, vp]
     lib.cbfssm_gp_predict_f64.argtypes = [C.POINTER(PackLayout), vp, vp, i64, vp, vp, vp]
     lib.cbfssm_backward_pass_partials.restype = i64
     lib.cbfssm_backward_pass_partials.argtypes = [C.POINTER(Problem)]

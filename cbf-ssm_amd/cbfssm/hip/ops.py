@@ -78,6 +78,23 @@ class GPPack:
         return fmean, fvar
 
 
+def prepare_pair(pack0, args0, pack1, args1, jitter=_l.JITTER):
+    """gp_f and gp_b in ONE launch (one workgroup each): args = (Z, lengthscales, variance, zeta_mean, zeta_var)."""
+    ptrs = []
+    keep = []
+    for pack, args in ((pack0, args0), (pack1, args1)):
+        dev = pack.buf.device
+        Z, ls, var, zm, zv = args
+        Z, ls, var = _f64(Z, dev), _f64(ls, dev).reshape(-1), _f64(var, dev).reshape(-1)
+        zm, zv = _f64(zm, dev), _f64(zv, dev)
+        assert Z.shape == (pack.M, pack.D) and ls.numel() == pack.D and var.numel() == 1
+        assert zm.shape == (pack.M, pack.Do) and zv.shape == (pack.M, pack.Do)
+        keep.append((Z, ls, var, zm, zv))
+        ptrs += [C.byref(pack.layout), _ptr(Z), _ptr(ls), _ptr(var), _ptr(zm), _ptr(zv), _ptr(pack.buf)]
+    rc = _l.load().cbfssm_gp_prepare2_f64(*ptrs, float(jitter), _stream())
+    _l.check(rc, 'cbfssm_gp_prepare2_f64')
+
+
 def kmm_chol(Z, lengthscales, variance, jitter=_l.JITTER):
     """RBF.K(zeta_pos) and cast_cholesky (gp_tf.py:33-65,129-130) -> (Kmm, L, info)."""
     dev = Z.device
@@ -178,9 +195,9 @@ class HipElbo:
 
     def prepare(self, params):
         p = {k: _f64(v, self.device) for k, v in params.items()}
-        for g, pack in (('f', self.pack_f), ('b', self.pack_b)):
-            pack.prepare(p[g + '.zeta_pos'], tf_forward(p[g + '.lengthscales_unc']), tf_forward(p[g + '.variance_unc']),
-                         p[g + '.zeta_mean'], tf_forward(p[g + '.zeta_var_unc']))
+        args = [(p[g + '.zeta_pos'], tf_forward(p[g + '.lengthscales_unc']), tf_forward(p[g + '.variance_unc']),
+                 p[g + '.zeta_mean'], tf_forward(p[g + '.zeta_var_unc'])) for g in 'fb']
+        prepare_pair(self.pack_f, args[0], self.pack_b, args[1])
         self.var_x = tf_forward(p['var_x_unc']).contiguous()
         self.var_y = tf_forward(p['var_y_unc']).contiguous()
 

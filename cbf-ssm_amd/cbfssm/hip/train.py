@@ -83,8 +83,8 @@ class HipElboGrad:
         prob = _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, cfg['recog_len'],
                                cfg['k_factor'], condition)
         c = self._constrained(p)
-        self.pack_f.prepare(p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar'])
-        self.pack_b.prepare(p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar'])
+        ops.prepare_pair(self.pack_f, (p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar']),
+                         self.pack_b, (p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar']))
         key = ('eval', B, T)
         if key not in self._ws:
             self._ws[key] = ops.ElboWorkspace(prob, dev, keep_h=False)
@@ -136,8 +136,8 @@ class HipElboGrad:
         prob = _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, cfg['recog_len'],
                                cfg['k_factor'], condition)
         c = self._constrained(p)
-        self.pack_f.prepare(p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar'])
-        self.pack_b.prepare(p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar'])
+        ops.prepare_pair(self.pack_f, (p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar']),
+                         self.pack_b, (p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar']))
         ws = self._workspace(prob)
         self.last_ws = ws
         hid_b, eps_b, eps_f = (_f64(noise[k], dev) for k in ('hid_b', 'eps_b', 'eps_f'))

@@ -46,6 +46,8 @@ struct RevArgs {
     double* gy2;           // (T,N,dob): written by the fwd reverse, read by the bwd reverse
     double* gpart;         // [workgroup][slab]
     int64_t slab;          // doubles per workgroup
+    int KSr;               // ceil(M / 4)
+    int nchunk;            // bwd: time chunks per run (grid.z), cut at resample boundaries
 };
 
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
@@ -59,10 +61,13 @@ struct Slab {
     static constexpr int total = small + 128;
 };
 
-template <int NBLK, int DK, bool BREG, int MODE>
+// BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the
+// ceil(M/4) k-steps that carry data); otherwise it streams from L2.
+template <int NBLK, int DK, bool BLDS, int MODE>
 __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
 {
     constexpr int RB = 1;
+    constexpr bool BREG = false;
     typedef Tile<NBLK, RB, DK, BREG> TT;
     constexpr int W = TT::W, NT = TT::NT, MP = TT::MP, KS = TT::KS;
     constexpr int JB = (4 * DK + 1 + 15) / 16;          // 16-row blocks covering the D inputs + the ones row
@@ -78,10 +83,10 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     double* A2t = Kt + MP * PD;                         // [MP][17]
     double* Fm = A2t + MP * PD;                         // [16][17]
     double* Fv = Fm + 16 * PD;                          // [16][17]
-    double* TS = Fv + 16 * PD;                          // [W][16][17]
-    double* part = TS + W * 16 * PD;                    // [W][max(2,JB)][4][64]
+    double* part = Fv + 16 * PD;                        // [W][max(2,JB)][4][64]
     constexpr int PSL = (JB > 2 ? JB : 2) * 256;
     double* red = part + W * PSL;                       // 64
+    double* Bl = red + 64;                              // BLDS: [NBLK][KSr][64]
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
@@ -93,19 +98,18 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     const int bq = c / S;
     const int run = (MODE == MODE_BWD) ? int(blockIdx.y) : 0;
     const int R = a.recog_len, P = 2 * R;
-    double* ts = TS + w * 16 * PD;
+    const int KSr = a.KSr;                              // k-steps of K^-1 that carry data: ceil(M/4)
 
     // ---- loop-invariant operands
     TT tile;
-    tile.load_operands(a.pk, w, l);
-    double muB[4], s2B[4], ZT[JB][4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        muB[s] = a.rk.muB[(w * 4 + s) * 64 + l];
-        s2B[s] = a.rk.s2B[(w * 4 + s) * 64 + l];
-#pragma unroll
-        for (int jb = 0; jb < JB; ++jb) ZT[jb][s] = a.rk.ZT[((w * JB + jb) * 4 + s) * 64 + l];
-    }
+    tile.template load_operands<false>(a.pk, w, l);
+    // (the small operand images muA/s2A/muB/s2B/ZT are re-read from L1/L2 where they are used: the VGPRs are
+    //  needed for the K^-1-adjoint accumulator)
+    const double* muBp = a.rk.muB + w * 256 + l;
+    const double* s2Bp = a.rk.s2B + w * 256 + l;
+    const double* ZTp = a.rk.ZT + w * JB * 256 + l;
+    const double* muAp = a.pk.muA + w * 256 + l;
+    const double* s2Ap = a.pk.s2A + w * 256 + l;
 
     // ---- accumulators of the parameter adjoints (whole pass)
     d4 gMu = {0, 0, 0, 0}, gS2 = {0, 0, 0, 0};
@@ -153,9 +157,25 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
 
     for (int i = tid; i < 4 * DK * PD; i += NT) xq[i] = 0.0;
     for (int i = tid; i < 16 * PD; i += NT) { Fm[i] = 0.0; Fv[i] = 0.0; }
+    if (BLDS) {
+        for (int s = 0; s < KSr; ++s) Bl[(w * KSr + s) * 64 + l] = a.pk.Bp[(w * KS + s) * 64 + l];
+    }
+    const double* bop = BLDS ? (Bl + w * KSr * 64 + l) : (a.pk.Bp + w * KS * 64 + l);
     __syncthreads();
 
-    const int nsteps = (MODE == MODE_FWD) ? (T - 1) : T;
+    // time range.  Backward runs: chunk z of run y covers whole resample-to-resample segments (the carried adjoint is
+    // zero at a segment start, cbfssm.py:133-136), so chunks are independent workgroups.
+    int t_begin = 0, nsteps = (MODE == MODE_FWD) ? (T - 1) : T;
+    if (MODE == MODE_BWD) {
+        const int o = run * R;
+        const int nseg = (T + o) / P + 1;                    // segment k starts at max(0, P*k - o), k = 0..nseg-1
+        const int z = blockIdx.z, nz = a.nchunk;
+        const int k0 = (z * nseg) / nz, k1 = ((z + 1) * nseg) / nz;
+        const int tb = (k0 == 0) ? 0 : min(T, P * k0 - o);
+        const int te = (k1 >= nseg) ? T : min(T, P * k1 - o);
+        t_begin = tb;
+        nsteps = max(0, te - tb);
+    }
     if (MODE == MODE_FWD && nsteps > 0) {
         // adjoint of x_{T-1}: only the log-likelihood sees it      (cbfssm.py:245-251)
 #pragma unroll
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     }
 
     for (int step = 0; step < nsteps; ++step) {
-        const int t = (MODE == MODE_FWD) ? (T - 2 - step) : step;
+        const int t = (MODE == MODE_FWD) ? (T - 2 - step) : (t_begin + step);
 
         // ---- A: GP input of step t from the saved trajectory
         double hcur[QPW];
@@ -246,28 +266,13 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         d4 a2;
         {
             d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            if constexpr (BREG) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const double b = Kt[(4 * s + g) * PD + nl];
-                    if (s & 1) acc1 = CBF_MFMA(tile.Breg[0][s], b, acc1);
-                    else acc0 = CBF_MFMA(tile.Breg[0][s], b, acc0);
-                }
-            } else {
-#pragma unroll 1
-                for (int s0 = 0; s0 < KS; s0 += 4) {
-                    double b[4], aop[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        b[j] = Kt[(4 * (s0 + j) + g) * PD + nl];
-                        aop[j] = tile.Bp[(w * KS + s0 + j) * 64 + l];
-                    }
-                    acc0 = CBF_MFMA(aop[0], b[0], acc0);
-                    acc1 = CBF_MFMA(aop[1], b[1], acc1);
-                    acc0 = CBF_MFMA(aop[2], b[2], acc0);
-                    acc1 = CBF_MFMA(aop[3], b[3], acc1);
-                }
+            int s = 0;
+#pragma unroll 2
+            for (; s + 1 < KSr; s += 2) {
+                acc0 = CBF_MFMA(bop[s * 64], Kt[(4 * s + g) * PD + nl], acc0);
+                acc1 = CBF_MFMA(bop[(s + 1) * 64], Kt[(4 * s + 4 + g) * PD + nl], acc1);
             }
+            if (s < KSr) acc0 = CBF_MFMA(bop[s * 64], Kt[(4 * s + g) * PD + nl], acc0);
             a2 = acc0 + acc1;
         }
         {
@@ -275,8 +280,8 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
             double q = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                P1 = CBF_MFMA(tile.muA[0][r], a2[r], P1);
-                P2 = CBF_MFMA(tile.s2A[0][r], a2[r] * a2[r], P2);
+                P1 = CBF_MFMA(muAp[r * 64], a2[r], P1);
+                P2 = CBF_MFMA(s2Ap[r * 64], a2[r] * a2[r], P2);
                 q = fma(kreg[r], a2[r], q);
             }
             q += __shfl_xor(q, 16);
@@ -382,29 +387,27 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
             d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                T1 = CBF_MFMA(muB[s], fmB[s], T1);
-                T2 = CBF_MFMA(s2B[s], fvB[s], T2);
+                T1 = CBF_MFMA(muBp[s * 64], fmB[s], T1);
+                T2 = CBF_MFMA(s2Bp[s * 64], fvB[s], T2);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                a2bar[r] = T1[r] + 2.0 * a2[r] * T2[r] - kreg[r] * fvsum;
-                A2t[(16 * w + 4 * r + g) * PD + nl] = a2bar[r];
-            }
+            for (int r = 0; r < 4; ++r) a2bar[r] = T1[r] + 2.0 * a2[r] * T2[r] - kreg[r] * fvsum;
         }
-        // wave-private transposes through LDS: C-layout (row g+4r, col nl) -> A-operand layout (row nl, k = 4s+g)
+        // 16x16 transposes through this wave's own rows of the A2bar tile (nobody else reads them before the next
+        // barrier): C-layout (row g+4r, col nl) -> A-operand layout (row nl, k = 4s+g)
         double a2T[4], abT[4];
+        double* own = A2t + 16 * w * PD;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ts[(g + 4 * r) * PD + nl] = a2[r];
+        for (int r = 0; r < 4; ++r) own[(g + 4 * r) * PD + nl] = a2[r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 4; ++s) a2T[s] = ts[nl * PD + 4 * s + g];
+        for (int s = 0; s < 4; ++s) a2T[s] = own[nl * PD + 4 * s + g];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ts[(g + 4 * r) * PD + nl] = a2bar[r];
+        for (int r = 0; r < 4; ++r) own[(g + 4 * r) * PD + nl] = a2bar[r];      // stays: the A2bar tile of phase F
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 4; ++s) abT[s] = ts[nl * PD + 4 * s + g];
-        __builtin_amdgcn_wave_barrier();
+        for (int s = 0; s < 4; ++s) abT[s] = own[nl * PD + 4 * s + g];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // B operands with the chain index as k: [n = 4s+g][col = nl]
@@ -427,28 +430,13 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         d4 ebar;
         {
             d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            if constexpr (BREG) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const double b = A2t[(4 * s + g) * PD + nl];
-                    if (s & 1) acc1 = CBF_MFMA(tile.Breg[0][s], b, acc1);
-                    else acc0 = CBF_MFMA(tile.Breg[0][s], b, acc0);
-                }
-            } else {
-#pragma unroll 1
-                for (int s0 = 0; s0 < KS; s0 += 4) {
-                    double b[4], aop[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        b[j] = A2t[(4 * (s0 + j) + g) * PD + nl];
-                        aop[j] = tile.Bp[(w * KS + s0 + j) * 64 + l];
-                    }
-                    acc0 = CBF_MFMA(aop[0], b[0], acc0);
-                    acc1 = CBF_MFMA(aop[1], b[1], acc1);
-                    acc0 = CBF_MFMA(aop[2], b[2], acc0);
-                    acc1 = CBF_MFMA(aop[3], b[3], acc1);
-                }
+            int s = 0;
+#pragma unroll 2
+            for (; s + 1 < KSr; s += 2) {
+                acc0 = CBF_MFMA(bop[s * 64], A2t[(4 * s + g) * PD + nl], acc0);
+                acc1 = CBF_MFMA(bop[(s + 1) * 64], A2t[(4 * s + 4 + g) * PD + nl], acc1);
             }
+            if (s < KSr) acc0 = CBF_MFMA(bop[s * 64], A2t[(4 * s + g) * PD + nl], acc0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) ebar[r] = (acc0[r] + acc1[r] - a2[r] * fvsum) * kreg[r];
         }
@@ -456,17 +444,17 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         for (int jb = 0; jb < JB; ++jb) {
             d4 xp = {0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xp = CBF_MFMA(ZT[jb][r], ebar[r], xp);   // rows j, k = m of this wave
+            for (int r = 0; r < 4; ++r) xp = CBF_MFMA(ZTp[(jb * 4 + r) * 64], ebar[r], xp);   // rows j, k = m of this wave
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[r];
         }
         double ebT[4];
+        double* ownk = Kt + 16 * w * PD;     // the K tile is dead after phase E: reuse this wave's rows for Ebar^T
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ts[(g + 4 * r) * PD + nl] = ebar[r];
+        for (int r = 0; r < 4; ++r) ownk[(g + 4 * r) * PD + nl] = ebar[r];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ebT[s] = ts[nl * PD + 4 * s + g];
-        __builtin_amdgcn_wave_barrier();
+        for (int s = 0; s < 4; ++s) ebT[s] = ownk[nl * PD + 4 * s + g];
 #pragma unroll
         for (int jb = 0; jb < JB; ++jb) {
             const int j = 16 * jb + nl;
@@ -542,7 +530,7 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     }
 
     // ---- write this workgroup's slab
-    double* slab = a.gpart + (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * a.slab;
+    double* slab = a.gpart + ((int64_t(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * a.slab;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         slab[SL::gMu + w * 256 + r * 64 + l] = gMu[r];

@@ -9,19 +9,31 @@ template <int NBLK, int DK>
 struct RevGeom {
     static constexpr int JB = (4 * DK + 1 + 15) / 16;
     static constexpr int PSL = (JB > 2 ? JB : 2) * 256;
-    static constexpr int LDS_DOUBLES = 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + NBLK * 16 * 17 + NBLK * PSL + 64;
+    static constexpr int LDS_BASE = 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + NBLK * PSL + 64;
+    static constexpr int LDS_LIMIT = 163840 / 8;
     static constexpr int SLAB = Slab<NBLK, JB>::total;
 };
 
 template <int NBLK, int DK, int MODE>
 int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
 {
-    constexpr bool BREG = false;   // K^-1 streams from L2 here: the VGPRs hold the K^-1-adjoint accumulator instead
-    const size_t lds = RevGeom<NBLK, DK>::LDS_DOUBLES * sizeof(double);
-    auto k = rev_kernel<NBLK, DK, BREG, MODE>;
-    int rc = set_lds(k, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(64 * NBLK), lds, st, a);
+    // K^-1 image in LDS when it fits next to the tiles (M <= 104 at NBLK = 7), else streamed from L2; the VGPRs hold
+    // the K^-1-adjoint accumulator either way
+    typedef RevGeom<NBLK, DK> G;
+    const int blds_doubles = NBLK * a.KSr * 64;
+    if (G::LDS_BASE + blds_doubles <= G::LDS_LIMIT) {
+        const size_t lds = size_t(G::LDS_BASE + blds_doubles) * sizeof(double);
+        auto k = rev_kernel<NBLK, DK, true, MODE>;
+        int rc = set_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(64 * NBLK), lds, st, a);
+    } else {
+        const size_t lds = size_t(G::LDS_BASE) * sizeof(double);
+        auto k = rev_kernel<NBLK, DK, false, MODE>;
+        int rc = set_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(64 * NBLK), lds, st, a);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
 }

@@ -48,10 +48,11 @@ struct PrepArgs {
     const double* zvar;
     double jitter;
     double* Kmm;           // M*M
-    double* A;             // M*M  -> L
-    double* G;             // M*M  -> L^-T
-    double* C;             // M*M  -> K^-1
+    double* Lout;          // M*M  lower Cholesky factor
+    double* Gout;          // M*M  L^-T (upper) or null
+    double* Kinv;          // M*M  or null
     double* Zs;            // M*D
+    double* gmat;          // global fallback for the working matrix when it does not fit LDS (M*(M+1)) or null
     // pack sections (null for kmm_chol only)
     double* Bp;
     double* Zp;
@@ -67,16 +68,30 @@ struct PrepArgs {
     double* info_out;      // kmm_chol: 1 double
 };
 
-#define PREP_NT 1024
+struct PrepArgs2 {
+    PrepArgs g[2];
+};
 
-__global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs a)
+#define PREP_NT 1024
+#define PREP_LDS_MAX_M 140   // (M | 1) * M doubles must fit the 160 KiB LDS next to the small arrays
+
+// One workgroup per GPModel (blockIdx.x).  The working matrix W (row stride LD, odd) starts as
+//   lower triangle + diagonal: K_mm + jitter I ;  strict upper triangle: 0 (the off-diagonal of the bordering identity)
+// and is swept column by column (right-looking Cholesky of [[K, I],[I, *]] restricted to the blocks that are needed):
+// afterwards column j of the lower part is L[:,j] * sqrt(piv_j) and row i of the strict upper part is
+// L^-T[i,:] * sqrt(piv) (unit diagonal implied).  One barrier per column.
+__global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
 {
+    const PrepArgs& a = aa.g[blockIdx.x];
+    extern __shared__ double smem[];
     __shared__ double Xs[CBFSSM_MAX_M];
     __shared__ double piv[CBFSSM_MAX_M];
     __shared__ double red[PREP_NT / 64];
     __shared__ int s_info;
     const int tid = threadIdx.x;
     const int M = a.M, D = a.D;
+    const int LD = M | 1;
+    double* Wm = (a.gmat != nullptr) ? a.gmat : smem;
     const int tx = tid & 31, ty = tid >> 5;   // 32 x 32 thread tile
 
     if (tid == 0) s_info = 0;
@@ -97,63 +112,70 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs a)
             const double d2 = -2.0 * dot + Xs[i] + Xs[k];                 // gp_tf.py:37-38, no clamp
             const double kv = var * exp(-0.5 * d2);                       // gp_tf.py:49
             a.Kmm[i * M + k] = kv;
-            a.A[i * M + k] = kv + ((i == k) ? a.jitter : 0.0);            // gp_tf.py:53
-            a.G[i * M + k] = (i == k) ? 1.0 : 0.0;
-            a.C[i * M + k] = 0.0;
+            Wm[i * LD + k] = (k < i) ? kv : ((k == i) ? kv + a.jitter : 0.0);   // gp_tf.py:53
         }
     }
     __syncthreads();
 
     double logdet = 0.0;
     for (int j = 0; j < M; ++j) {
-        const double p = a.A[j * M + j];
+        const double p = Wm[j * LD + j];
         if (tid == 0) {
             piv[j] = p;
             if (!(p > 0.0) && s_info == 0) s_info = j + 1;
             logdet += log(p);
         }
         const double rp = 1.0 / p;
-        // trailing update of K part (lower triangle, rows/cols > j)
+        // trailing update of the K part (lower triangle incl. diagonal, rows/cols > j)
         for (int i = j + 1 + ty; i < M; i += 32) {
-            const double aij = a.A[i * M + j] * rp;
-            for (int k = j + 1 + tx; k <= i; k += 32) a.A[i * M + k] -= aij * a.A[k * M + j];
+            const double aij = Wm[i * LD + j] * rp;
+            for (int k = j + 1 + tx; k <= i; k += 32) Wm[i * LD + k] -= aij * Wm[k * LD + j];
         }
-        // border block G (rows <= j have a non-zero in column j)
+        // border rows i <= j of L^-T (strict upper part; entry (j, j) is the implied 1)
         for (int i = ty; i <= j; i += 32) {
-            const double gij = a.G[i * M + j] * rp;
-            for (int k = j + 1 + tx; k < M; k += 32) a.G[i * M + k] -= gij * a.A[k * M + j];
-        }
-        // Schur complement block C = -K^-1 accumulates (lower triangle)
-        for (int i = ty; i <= j; i += 32) {
-            const double gij = a.G[i * M + j] * rp;
-            for (int k = tx; k <= i; k += 32) a.C[i * M + k] -= gij * a.G[k * M + j];
+            const double gij = ((i < j) ? Wm[i * LD + j] : 1.0) * rp;
+            for (int k = j + 1 + tx; k < M; k += 32) Wm[i * LD + k] -= gij * Wm[k * LD + j];
         }
         __syncthreads();
     }
-    // scale columns: L = A diag(piv)^-1/2, L^-T = G diag(piv)^-1/2; K^-1 = -C, symmetric
+    // outputs: L = W_lower diag(piv)^-1/2, L^-T = W_upper diag(piv)^-1/2 (diagonal 1/sqrt(piv))
     for (int i = ty; i < M; i += 32) {
         for (int k = tx; k < M; k += 32) {
-            const double rs = 1.0 / sqrt(piv[k]);
-            const double lv = (k < i) ? a.A[i * M + k] * rs : ((k == i) ? sqrt(piv[k]) : 0.0);
-            const double gv = (k >= i) ? a.G[i * M + k] * rs : 0.0;
-            a.A[i * M + k] = lv;
-            a.G[i * M + k] = gv;
-            if (k > i) a.C[i * M + k] = -a.C[k * M + i];
+            const double sp = sqrt(piv[k]);
+            const double w = Wm[i * LD + k];
+            a.Lout[i * M + k] = (k < i) ? w / sp : ((k == i) ? sp : 0.0);
+            const double gv = (k > i) ? w / sp : ((k == i) ? 1.0 / sp : 0.0);
+            if (a.Gout) a.Gout[i * M + k] = gv;
         }
     }
     __syncthreads();
-    for (int i = ty; i < M; i += 32)
-        for (int k = tx; k <= i; k += 32) a.C[i * M + k] = -a.C[i * M + k];
-    __syncthreads();
     if (a.info_out && tid == 0) a.info_out[0] = double(s_info);
+    if (!a.Kinv) return;
+    // scale the upper part in place (own element only), then K^-1 = G G^T, G = L^-T upper triangular
+    for (int i = ty; i < M; i += 32)
+        for (int k = i + tx; k < M; k += 32) {
+            const double sp = sqrt(piv[k]);
+            Wm[i * LD + k] = (k > i) ? Wm[i * LD + k] / sp : 1.0 / sp;    // diagonal now holds G[i][i]
+        }
+    __syncthreads();
+    for (int i = ty; i < M; i += 32) {
+        for (int k = tx; k <= i; k += 32) {
+            double sum = 0.0;
+            for (int q = i; q < M; ++q) sum += Wm[i * LD + q] * Wm[k * LD + q];   // q >= max(i,k) = i
+            a.Kinv[i * M + k] = sum;
+            a.Kinv[k * M + i] = sum;
+        }
+    }
+    __syncthreads();
     if (!a.Bp) return;
+    const double* Cm = a.Kinv;
 
     // ---- operand images for the time-loop kernels
     const int Do = a.Do, NBLK = a.NBLK, DK = a.DK, Mp = 16 * NBLK, KS = Mp / 4;
     for (int i = tid; i < NBLK * KS * 64; i += PREP_NT) {
         const int l = i & 63, s = (i >> 6) % KS, rb = (i >> 6) / KS;
         const int row = 16 * rb + (l & 15), col = 4 * s + (l >> 4);
-        a.Bp[i] = (row < M && col < M) ? a.C[row * M + col] : 0.0;
+        a.Bp[i] = (row < M && col < M) ? Cm[row * M + col] : 0.0;
     }
     for (int i = tid; i < NBLK * DK * 64; i += PREP_NT) {
         const int l = i & 63, s = (i >> 6) % DK, rb = (i >> 6) / DK;
@@ -191,9 +213,9 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs a)
     for (int i = tid; i < M * Do; i += PREP_NT) {
         const int m = i / Do, d = i % Do;
         double kmu = 0.0;
-        for (int k = 0; k < M; ++k) kmu += a.C[m * M + k] * a.zmean[k * Do + d];
+        for (int k = 0; k < M; ++k) kmu += Cm[m * M + k] * a.zmean[k * Do + d];
         const double s2 = a.zvar[m * Do + d];
-        acc += a.C[m * M + m] * s2 + a.zmean[m * Do + d] * kmu - log(s2);
+        acc += Cm[m * M + m] * s2 + a.zmean[m * Do + d] * kmu - log(s2);
     }
     const double tot = block_sum(acc, red, tid, PREP_NT);
     if (tid == 0) {
@@ -203,6 +225,19 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs a)
         a.scal[CBFSSM_SCAL_INFO] = double(s_info);
         for (int i = 4; i < CBFSSM_SCAL_COUNT; ++i) a.scal[i] = 0.0;
     }
+}
+
+static int launch_prepare(PrepArgs2& aa, int n, int maxM, hipStream_t st)
+{
+    size_t lds = 0;
+    if (maxM <= PREP_LDS_MAX_M) lds = size_t(maxM | 1) * maxM * sizeof(double);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prepare_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(-int(e) - 1000, "prepare: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(prepare_kernel, dim3(n), dim3(PREP_NT), lds, st, aa);
+    return check_launch("gp_prepare");
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -408,6 +443,7 @@ int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out)
     out->s2B = take(int64_t(nblk) * 256);
     out->ZT = take(int64_t(nblk) * out->JB * 256);
     out->rev_slab = rev_slab(nblk, dk);
+    out->work = take(M > PREP_LDS_MAX_M ? int64_t(M) * (M | 1) : 0);
     out->total = o;
     return 0;
 }
@@ -417,30 +453,54 @@ int cbfssm_kmm_chol_f64(int M, int D, const double* Z, const double* lengthscale
 {
     if (M < 1 || M > CBFSSM_MAX_M || D < 1 || D > CBFSSM_MAX_DIN) return fail(-1, "bad M/D");
     if (!Z || !lengthscales || !variance || !Kmm || !L || !info || !work) return fail(-1, "null pointer");
-    PrepArgs a;
-    memset(&a, 0, sizeof(a));
+    PrepArgs2 aa;
+    memset(&aa, 0, sizeof(aa));
+    PrepArgs& a = aa.g[0];
     a.M = M; a.D = D; a.Z = Z; a.ls = lengthscales; a.var = variance; a.jitter = jitter;
-    a.Kmm = Kmm; a.A = L; a.G = work; a.C = work + int64_t(M) * M; a.Zs = work + 2 * int64_t(M) * M;
+    a.Kmm = Kmm; a.Lout = L; a.Zs = work; a.gmat = (M > PREP_LDS_MAX_M) ? work + int64_t(M) * D : nullptr;
     a.info_out = info;
-    hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(PREP_NT), 0, (hipStream_t)stream, a);
-    return check_launch("kmm_chol");
+    return launch_prepare(aa, 1, M, (hipStream_t)stream);
+}
+
+static int fill_prep(PrepArgs& a, const cbfssm_pack_layout* L, const double* Z, const double* lengthscales,
+                     const double* variance, const double* zeta_mean, const double* zeta_var, double jitter,
+                     double* pack)
+{
+    if (!L || !Z || !lengthscales || !variance || !zeta_mean || !zeta_var || !pack) return fail(-1, "null pointer");
+    a.M = L->M; a.D = L->D; a.Do = L->Do; a.NBLK = L->NBLK; a.DK = L->DK;
+    a.Z = Z; a.ls = lengthscales; a.var = variance; a.zmean = zeta_mean; a.zvar = zeta_var; a.jitter = jitter;
+    a.Kmm = pack + L->Kmm; a.Lout = pack + L->L; a.Gout = pack + L->Linvt; a.Kinv = pack + L->Kinv;
+    a.Zs = pack + L->Zs;
+    a.gmat = (L->M > PREP_LDS_MAX_M) ? pack + L->work : nullptr;
+    a.Bp = pack + L->Bp; a.Zp = pack + L->Zp; a.cz = pack + L->cz; a.muA = pack + L->muA; a.s2A = pack + L->s2A;
+    a.invl = pack + L->invl; a.scal = pack + L->scal;
+    a.muB = pack + L->muB; a.s2B = pack + L->s2B; a.ZT = pack + L->ZT; a.JB = L->JB;
+    return 0;
 }
 
 int cbfssm_gp_prepare_f64(const cbfssm_pack_layout* L, const double* Z, const double* lengthscales,
                           const double* variance, const double* zeta_mean, const double* zeta_var, double jitter,
                           double* pack, void* stream)
 {
-    if (!L || !Z || !lengthscales || !variance || !zeta_mean || !zeta_var || !pack) return fail(-1, "null pointer");
-    PrepArgs a;
-    memset(&a, 0, sizeof(a));
-    a.M = L->M; a.D = L->D; a.Do = L->Do; a.NBLK = L->NBLK; a.DK = L->DK;
-    a.Z = Z; a.ls = lengthscales; a.var = variance; a.zmean = zeta_mean; a.zvar = zeta_var; a.jitter = jitter;
-    a.Kmm = pack + L->Kmm; a.A = pack + L->L; a.G = pack + L->Linvt; a.C = pack + L->Kinv; a.Zs = pack + L->Zs;
-    a.Bp = pack + L->Bp; a.Zp = pack + L->Zp; a.cz = pack + L->cz; a.muA = pack + L->muA; a.s2A = pack + L->s2A;
-    a.invl = pack + L->invl; a.scal = pack + L->scal;
-    a.muB = pack + L->muB; a.s2B = pack + L->s2B; a.ZT = pack + L->ZT; a.JB = L->JB;
-    hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(PREP_NT), 0, (hipStream_t)stream, a);
-    return check_launch("gp_prepare");
+    PrepArgs2 aa;
+    memset(&aa, 0, sizeof(aa));
+    int rc = fill_prep(aa.g[0], L, Z, lengthscales, variance, zeta_mean, zeta_var, jitter, pack);
+    if (rc) return rc;
+    return launch_prepare(aa, 1, L->M, (hipStream_t)stream);
+}
+
+int cbfssm_gp_prepare2_f64(const cbfssm_pack_layout* L0, const double* Z0, const double* ls0, const double* var0,
+                           const double* zmean0, const double* zvar0, double* pack0,
+                           const cbfssm_pack_layout* L1, const double* Z1, const double* ls1, const double* var1,
+                           const double* zmean1, const double* zvar1, double* pack1, double jitter, void* stream)
+{
+    PrepArgs2 aa;
+    memset(&aa, 0, sizeof(aa));
+    int rc = fill_prep(aa.g[0], L0, Z0, ls0, var0, zmean0, zvar0, jitter, pack0);
+    if (rc) return rc;
+    rc = fill_prep(aa.g[1], L1, Z1, ls1, var1, zmean1, zvar1, jitter, pack1);
+    if (rc) return rc;
+    return launch_prepare(aa, 2, L0->M > L1->M ? L0->M : L1->M, (hipStream_t)stream);
 }
 
 int cbfssm_gp_predict_f64(const cbfssm_pack_layout* L, const double* pack, const double* X, int64_t npts,
@@ -549,10 +609,23 @@ int cbfssm_elbo_combine_f64(const cbfssm_problem* p, double lambda0, double lamb
     return check_launch("elbo_combine");
 }
 
+static int rev_chunks(const cbfssm_problem* p)
+{
+    // enough workgroups for ~5 rounds over 256 CUs (one adjoint workgroup per CU), never more chunks than segments
+    const int64_t groups = (int64_t(p->B) * p->S + 15) / 16;
+    const int P = 2 * p->recog_len;
+    const int nseg = p->T / P + 1;
+    int64_t c = (1280 + 2 * groups - 1) / (2 * groups);
+    if (c > nseg) c = nseg;
+    if (c < 1) c = 1;
+    if (c > 64) c = 64;
+    return int(c);
+}
+
 int64_t cbfssm_rev_workgroups(const cbfssm_problem* p, int backward_runs)
 {
-    if (!p) return -1;
-    return (int64_t(p->B) * p->S + 15) / 16 * (backward_runs ? 2 : 1);
+    if (!p || p->recog_len < 1) return -1;
+    return (int64_t(p->B) * p->S + 15) / 16 * (backward_runs ? 2 * rev_chunks(p) : 1);
 }
 
 static int fill_rev(RevArgs& a, const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack, int Do)
@@ -564,6 +637,7 @@ static int fill_rev(RevArgs& a, const cbfssm_problem* p, const cbfssm_pack_layou
     a.dim_x = p->dim_x; a.dim_u = p->dim_u; a.dim_y = p->dim_y; a.Do = Do; a.D = L->D;
     a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = p->k_factor;
     a.slab = L->rev_slab;
+    a.KSr = (L->M + 3) / 4;
     if (L->rev_slab <= 0)
         return fail(-3, "no adjoint kernel for M=%d (tile height %d): training supports M <= 112 in this build",
                     L->M, L->NBLK);
@@ -604,7 +678,8 @@ int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layo
     if (rc) return rc;
     a.cE = cE; a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.h_all = h_all;
     a.gy2 = const_cast<double*>(gy2); a.gpart = gpart;
-    dim3 grid(unsigned((a.N + 15) / 16), 2);
+    a.nchunk = rev_chunks(p);
+    dim3 grid(unsigned((a.N + 15) / 16), 2, unsigned(a.nchunk));
     rc = dispatch_rev(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
     if (rc) return fail(rc, "backward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;

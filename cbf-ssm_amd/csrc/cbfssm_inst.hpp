@@ -10,7 +10,7 @@ namespace cbfssm {
 //                          register file of a CU: 13 blocks x 52 k-steps x 2 VGPRs = 1352 of 2048).
 template <int NBLK>
 struct Cfg {
-    static constexpr int RB = (NBLK > 16) ? 2 : 1;
+    static constexpr int RB = (NBLK > 16) ? 2 : 1;   // (RB = 2 at NBLK = 7 -- 4 waves, 380 VGPRs, one wave per SIMD -- measured 2.6x slower)
     static constexpr bool BREG = (NBLK <= 7);
 };
 

@@ -84,6 +84,7 @@ struct Tile {
     const double* Bp;
     double sigma2;
 
+    template <bool WITH_EPI = true>
     __device__ __forceinline__ void load_operands(const PackPtrs& pk, int w, int l)
     {
         Bp = pk.Bp;
@@ -98,8 +99,10 @@ struct Tile {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 czr[i][r] = ok ? pk.cz[16 * rbc + 4 * r + (l >> 4)] : -1e30;
-                muA[i][r] = ok ? pk.muA[(rbc * 4 + r) * 64 + l] : 0.0;
-                s2A[i][r] = ok ? pk.s2A[(rbc * 4 + r) * 64 + l] : 0.0;
+                if (WITH_EPI) {
+                    muA[i][r] = ok ? pk.muA[(rbc * 4 + r) * 64 + l] : 0.0;
+                    s2A[i][r] = ok ? pk.s2A[(rbc * 4 + r) * 64 + l] : 0.0;
+                }
             }
             if (BREG) {
 #pragma unroll

@@ -56,6 +56,7 @@ typedef struct {
     int64_t s2B;      /* [NBLK][4][64]   zeta_var, same image                                                        */
     int64_t ZT;       /* [NBLK][JB][4][64] (Z/lengthscale)^T as A-operand image A[row j][k = m]; row D = ones        */
     int64_t rev_slab; /* doubles of one adjoint partial slab (0: no adjoint kernel for this tile height)            */
+    int64_t work;     /* [M][M|1]        factorisation workspace when M is too large for LDS                        */
     int32_t M, D, Do, NBLK, DK, Mp, Dp, KS, JB, pad_;
 } cbfssm_pack_layout;
 
@@ -80,7 +81,7 @@ int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out);
  * K_mm and its Cholesky factor.
  * Replaces: RBF.K(zeta_pos) (gp_tf.py:33-49,129) and cast_cholesky/_jitter_cholesky (gp_tf.py:52-65,130).
  *   Z (M,D), lengthscales (D), variance (1)  ->  Kmm (M,M) without jitter, L (M,M) lower (upper part zero),
- *   info (1 double: 0 or the failing leading minor).  work: >= 3*M*M doubles.
+ *   info (1 double: 0 or the failing leading minor).  work: >= M*D + M*(M+1) doubles.
  */
 int cbfssm_kmm_chol_f64(int M, int D, const double* Z, const double* lengthscales, const double* variance,
                         double jitter, double* Kmm, double* L, double* info, double* work, void* stream);
@@ -95,6 +96,13 @@ int cbfssm_kmm_chol_f64(int M, int D, const double* Z, const double* lengthscale
 int cbfssm_gp_prepare_f64(const cbfssm_pack_layout* layout, const double* Z, const double* lengthscales,
                           const double* variance, const double* zeta_mean, const double* zeta_var,
                           double jitter, double* pack, void* stream);
+
+/* The same for two GPModels in one launch (gp_f and gp_b of CBFSSM._setup_vars, cbfssm.py:30-48): one workgroup each. */
+int cbfssm_gp_prepare2_f64(const cbfssm_pack_layout* layout0, const double* Z0, const double* lengthscales0,
+                           const double* variance0, const double* zeta_mean0, const double* zeta_var0, double* pack0,
+                           const cbfssm_pack_layout* layout1, const double* Z1, const double* lengthscales1,
+                           const double* variance1, const double* zeta_mean1, const double* zeta_var1, double* pack1,
+                           double jitter, void* stream);
 
 /*
  * GPModel.predict(Xnew) (gp_tf.py:132-161): X (npts, D) -> fmean (npts, Do), fvar (npts, Do).
