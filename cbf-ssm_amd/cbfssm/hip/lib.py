@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libcbfssm_hip.so'))
+LIB_PATH = os.environ.get('CBFSSM_HIP_LIB') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libcbfssm_hip.so'))
 
 SCAL_SIGMA2, SCAL_LOGDET, SCAL_KLZ, SCAL_INFO, SCAL_COUNT = 0, 1, 2, 3, 8
 JITTER = 1e-8   # cbfssm/model/gp_tf.py:57

@@ -18,6 +18,42 @@
 
 namespace cbfssm {
 
+// Diagnostic build only (-DCBF_REV_STAMPS): per-phase cycle shares of the adjoint step, compute vs barrier wait, summed
+// over the steps of a pass by lane 0 of every wave into otherwise unused slots of the slab's scalar block
+// (wave 0 -> compute[7] at 100.., wait[7] at 107..; last wave -> 114.., 121..; wave 0 sub-phase marks at 128..).
+// Never defined in the shipped library.
+#ifdef CBF_REV_STAMPS
+#define CBF_STAMP_DECL                                                                                      \
+    unsigned long long st_prev, st_mprev = 0, st_c[7] = {0, 0, 0, 0, 0, 0, 0}, st_w[7] = {0, 0, 0, 0, 0, 0, 0}, \
+                                              st_m[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define CBF_STAMP_READ(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#define CBF_STAMP_START() CBF_STAMP_READ(st_prev)
+#define CBF_STAMP_BARRIER(i)                 \
+    {                                        \
+        unsigned long long t1_, t2_;         \
+        CBF_STAMP_READ(t1_);                 \
+        __syncthreads();                     \
+        CBF_STAMP_READ(t2_);                 \
+        st_c[i] += t1_ - st_prev;            \
+        st_w[i] += t2_ - t1_;                \
+        st_prev = t2_;                       \
+    }
+#define CBF_STAMP_MARK(i)                    \
+    {                                        \
+        unsigned long long t1_;              \
+        CBF_STAMP_READ(t1_);                 \
+        st_m[i] += t1_ - st_mprev;           \
+        st_mprev = t1_;                      \
+    }
+#define CBF_STAMP_MARK0() CBF_STAMP_READ(st_mprev)
+#else
+#define CBF_STAMP_DECL
+#define CBF_STAMP_START()
+#define CBF_STAMP_BARRIER(i) __syncthreads()
+#define CBF_STAMP_MARK(i)
+#define CBF_STAMP_MARK0()
+#endif
+
 struct RevPackPtrs {
     const double* muB;   // [NBLK][4][64]   A[row m][k = d]
     const double* s2B;
@@ -58,7 +94,7 @@ struct Slab {
     static constexpr int gB = gS2 + NBLK * 256;                // [NBLK][NBLK][256]
     static constexpr int gZ = gB + NBLK * NBLK * 256;          // [NBLK][JB][256]
     static constexpr int small = gZ + NBLK * JB * 256;         // 128: [0,16) gvx, [16,32) gvy, [32,32+16*JB) glx, 96 gsig, 97 glogsig
-    static constexpr int total = small + 128;
+    static constexpr int total = small + 192;   // [128,192): diagnostic sub-phase stamps (CBF_REV_STAMPS builds only)
 };
 
 // BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the
@@ -189,6 +225,8 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         }
     }
 
+    CBF_STAMP_DECL;
+    CBF_STAMP_START();
     for (int step = 0; step < nsteps; ++step) {
         const int t = (MODE == MODE_FWD) ? (T - 2 - step) : (t_begin + step);
 
@@ -236,7 +274,7 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
                 gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
             }
         }
-        __syncthreads();
+        CBF_STAMP_BARRIER(0);
 
         // ---- B: kernel tile (rows of this wave)
         double bx[DK], xx = 0.0;
@@ -260,9 +298,13 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
                 Kt[(16 * w + 4 * r + g) * PD + nl] = kreg[r];
             }
         }
-        __syncthreads();
+        CBF_STAMP_BARRIER(1);
 
         // ---- C: A2 rows of this wave, P1/P2
+        CBF_STAMP_MARK0();
+        double mA[4], sA[4];      // epilogue operands: fetched now, used after the K^-1 K loop
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mA[r] = muAp[r * 64]; sA[r] = s2Ap[r * 64]; }
         d4 a2;
         {
             d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
@@ -275,13 +317,14 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
             if (s < KSr) acc0 = CBF_MFMA(bop[s * 64], Kt[(4 * s + g) * PD + nl], acc0);
             a2 = acc0 + acc1;
         }
+        CBF_STAMP_MARK(0);
         {
             d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
             double q = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                P1 = CBF_MFMA(muAp[r * 64], a2[r], P1);
-                P2 = CBF_MFMA(s2Ap[r * 64], a2[r] * a2[r], P2);
+                P1 = CBF_MFMA(mA[r], a2[r], P1);
+                P2 = CBF_MFMA(sA[r], a2[r] * a2[r], P2);
                 q = fma(kreg[r], a2[r], q);
             }
             q += __shfl_xor(q, 16);
@@ -292,7 +335,11 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
                 part[w * PSL + (1 * 4 + r) * 64 + l] = P2[r] - q;
             }
         }
-        __syncthreads();
+        double mB[4], sB[4];      // operands of phase E: fetched now, they land while phase D runs
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { mB[s] = muBp[s * 64]; sB[s] = s2Bp[s * 64]; }
+        CBF_STAMP_MARK(1);
+        CBF_STAMP_BARRIER(2);
 
         // ---- D: adjoint of the step epilogue
 #pragma unroll
@@ -369,9 +416,10 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
                 }
             }
         }
-        __syncthreads();
+        CBF_STAMP_BARRIER(3);
 
         // ---- E: A2bar, and the parameter adjoints that contract over the 16 chains
+        CBF_STAMP_MARK0();
         double fvsum = 0.0;
         double fmB[4], fvB[4];
 #pragma unroll
@@ -387,12 +435,13 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
             d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                T1 = CBF_MFMA(muBp[s * 64], fmB[s], T1);
-                T2 = CBF_MFMA(s2Bp[s * 64], fvB[s], T2);
+                T1 = CBF_MFMA(mB[s], fmB[s], T1);
+                T2 = CBF_MFMA(sB[s], fvB[s], T2);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) a2bar[r] = T1[r] + 2.0 * a2[r] * T2[r] - kreg[r] * fvsum;
         }
+        CBF_STAMP_MARK(2);
         // 16x16 transposes through this wave's own rows of the A2bar tile (nobody else reads them before the next
         // barrier): C-layout (row g+4r, col nl) -> A-operand layout (row nl, k = 4s+g)
         double a2T[4], abT[4];
@@ -408,6 +457,7 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < 4; ++s) abT[s] = own[nl * PD + 4 * s + g];
+        CBF_STAMP_MARK(3);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // B operands with the chain index as k: [n = 4s+g][col = nl]
@@ -416,6 +466,7 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
             gMu = CBF_MFMA(a2T[s], fmT, gMu);                       // mubar[m][d]  += A2[m][n] Fm[d][n]
             gS2 = CBF_MFMA(a2T[s] * a2T[s], fvT, gS2);              // s2bar[m][d]  += A2[m][n]^2 Fv[d][n]
         }
+        CBF_STAMP_MARK(4);
 #pragma unroll
         for (int cb = 0; cb < NBLK; ++cb) {
 #pragma unroll
@@ -424,9 +475,16 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
                 gB[cb] = CBF_MFMA(abT[s], kT, gB[cb]);              // Kinvbar[m'][m] += A2bar[m'][n] K[m][n]
             }
         }
-        __syncthreads();
+        CBF_STAMP_MARK(5);
+        CBF_STAMP_BARRIER(4);
 
         // ---- F: Kbar, Ebar, input adjoint partials, Zbar~
+        CBF_STAMP_MARK0();
+        double zT[JB][4];
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zT[jb][r] = ZTp[(jb * 4 + r) * 64];
         d4 ebar;
         {
             d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
@@ -440,14 +498,16 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ebar[r] = (acc0[r] + acc1[r] - a2[r] * fvsum) * kreg[r];
         }
+        CBF_STAMP_MARK(6);
 #pragma unroll
         for (int jb = 0; jb < JB; ++jb) {
             d4 xp = {0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xp = CBF_MFMA(ZTp[(jb * 4 + r) * 64], ebar[r], xp);   // rows j, k = m of this wave
+            for (int r = 0; r < 4; ++r) xp = CBF_MFMA(zT[jb][r], ebar[r], xp);   // rows j, k = m of this wave
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[r];
         }
+        CBF_STAMP_MARK(7);
         double ebT[4];
         double* ownk = Kt + 16 * w * PD;     // the K tile is dead after phase E: reuse this wave's rows for Ebar^T
 #pragma unroll
@@ -465,7 +525,8 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
                 gZ[jb] = CBF_MFMA(ebT[s], xT, gZ[jb]);                            // Zbar~[m][j] += Ebar[m][n] x~[j][n]
             }
         }
-        __syncthreads();
+        CBF_STAMP_MARK(8);
+        CBF_STAMP_BARRIER(5);
 
         // ---- G: input adjoint, carried to the next reverse step
         double esum = 0.0;   // colsum of Ebar for this lane's chain = row D of the xbar tile
@@ -517,7 +578,7 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
             }
         }
         // (the barrier at the top of the next step orders the part/xq reads above against the next writes)
-        __syncthreads();
+        CBF_STAMP_BARRIER(6);
     }
 
     if (MODE == MODE_FWD && nsteps == 0) {
@@ -568,6 +629,16 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         slab[SL::small + 96] = s1;
         slab[SL::small + 97] = s2;
     }
+#ifdef CBF_REV_STAMPS
+    if (l == 0 && (w == 0 || w == W - 1)) {
+        const int o = (w == 0) ? 100 : 114;
+        for (int i = 0; i < 7; ++i) {
+            slab[SL::small + o + i] = double(st_c[i]);
+            slab[SL::small + o + 7 + i] = double(st_w[i]);
+        }
+        if (w == 0) for (int i = 0; i < 12; ++i) slab[SL::small + 128 + i] = double(st_m[i]);
+    }
+#endif
 }
 
 }  // namespace cbfssm
