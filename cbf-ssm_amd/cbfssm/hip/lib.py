@@ -18,14 +18,15 @@ SYMBOLS = (
     'cbfssm_gp_predict_f64', 'cbfssm_backward_pass_partials', 'cbfssm_backward_pass_f64',
     'cbfssm_forward_pass_partials', 'cbfssm_forward_pass_f64', 'cbfssm_loglik_moments_f64',
     'cbfssm_elbo_combine_f64', 'cbfssm_rev_workgroups', 'cbfssm_forward_pass_bwd_f64',
-    'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64',
+    'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64', 'cbfssm_bwd_segments', 'cbfssm_forward_pass_bwd_ex_f64',
+    'cbfssm_backward_pass_bwd_ex_f64',
 )
 
 
 class PackLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('total', 'Bp', 'Zp', 'cz', 'muA', 's2A', 'invl', 'scal', 'Kmm', 'L', 'Kinv',
                                           'Linvt', 'Zs', 'muB', 's2B', 'ZT', 'rev_slab', 'work')] + \
-               [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS', 'JB', 'pad_')]
+               [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS', 'JB', 'rev_stash')]
 
 
 class Problem(C.Structure):
@@ -70,10 +71,13 @@ def load():
     lib.cbfssm_rev_workgroups.argtypes = [C.POINTER(Problem), ip]
     lib.cbfssm_forward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, vp, vp]
     lib.cbfssm_backward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, vp]
+    lib.cbfssm_bwd_segments.argtypes = [C.POINTER(Problem)]
+    lib.cbfssm_forward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, vp, ip, ip, vp, vp, vp, i64, vp])
+    lib.cbfssm_backward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, ip, ip, ip, vp, vp, i64, vp])
     lib.cbfssm_reduce_partials_f64.argtypes = [vp, i64, i64, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int or name.endswith('_f64') or name == 'cbfssm_gp_pack_layout':
+        if fn.restype is C.c_int or name.endswith('_f64') or name in ('cbfssm_gp_pack_layout', 'cbfssm_bwd_segments'):
             fn.restype = ip
     _lib = lib
     return lib

@@ -46,6 +46,10 @@ class HipElboGrad:
         self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device)
         self.pack_b = GPPack(self.M, self.D, self.dob, self.device)
         self.has_adjoint = all(pk.layout.rev_slab > 0 for pk in (self.pack_f, self.pack_b))
+        # tile heights above 112 inducing points run the adjoint in "stash mode" (include/cbfssm_hip.h)
+        self.stash = bool(self.pack_f.layout.rev_stash)
+        self.stash_bytes = int(float(config.get('adjoint_stash_gib', 4.0)) * 2 ** 30)
+        self._stash_buf = None
         if require_adjoint:
             self._need_adjoint()
         self.slab_f = max(0, int(self.pack_f.layout.rev_slab))
@@ -58,9 +62,7 @@ class HipElboGrad:
 
     def _need_adjoint(self):
         if not self.has_adjoint:
-            raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d): training supports M <= 112 in this '
-                                    'build; evaluation works for every M <= 320'
-                                    % (self.M, self.pack_f.layout.NBLK))
+            raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d)' % (self.M, self.pack_f.layout.NBLK))
 
     # ---- forward evaluation (keeps what the adjoint needs)
     def _constrained(self, p):
@@ -118,6 +120,9 @@ class HipElboGrad:
             n_b = int(lib.cbfssm_rev_workgroups(C.byref(prob), 1))
             f = dict(dtype=torch.float64, device=self.device)
             ws.gy2 = torch.zeros_like(ws.y2)
+            if self.stash:
+                n_b = 2 * n_f          # one launch per segment range, grid.z = 1
+                ws.gx_carry = torch.zeros(prob.B * prob.S, prob.dim_x, **f)
             ws.gpart_f = torch.zeros(n_f * self.slab_f, **f)
             ws.gpart_b = torch.zeros(n_b * self.slab_b, **f)
             ws.n_f, ws.n_b = n_f, n_b
@@ -148,20 +153,23 @@ class HipElboGrad:
         st = _stream()
         pb = C.byref(prob)
         cL, cE = float(lf[0]) / self.S, float(lf[1]) / self.S
-        rc = lib.cbfssm_forward_pass_bwd_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf), _ptr(c['var_x']),
-                                             _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
-                                             _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), cL, _ptr(ws.gy2),
-                                             _ptr(ws.gpart_f), st)
-        _l.check(rc, 'cbfssm_forward_pass_bwd_f64')
-        rc = lib.cbfssm_backward_pass_bwd_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
-                                              _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
-                                              _ptr(ws.h_all), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), st)
-        _l.check(rc, 'cbfssm_backward_pass_bwd_f64')
         red = self.red
         sf, sb = self.slab_f, self.slab_b
-        _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
-        _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
-
+        gB_f = gB_b = None
+        if not self.stash:
+            rc = lib.cbfssm_forward_pass_bwd_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
+                                                 _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
+                                                 _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), cL,
+                                                 _ptr(ws.gy2), _ptr(ws.gpart_f), st)
+            _l.check(rc, 'cbfssm_forward_pass_bwd_f64')
+            rc = lib.cbfssm_backward_pass_bwd_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
+                                                  _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
+                                                  _ptr(ws.h_all), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), st)
+            _l.check(rc, 'cbfssm_backward_pass_bwd_f64')
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
+        else:
+            gB_f, gB_b = self._adjoint_stash(prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red)
         # ---- data scalars and the log-likelihood's pull on var_y (cbfssm.py:245-251)
         vy = c['var_y'][:self.dim_y]
         ll_d = ws.ll_part.view(B * T, self.dim_y).sum(0)
@@ -172,14 +180,18 @@ class HipElboGrad:
         tail[3:] = gvy_ll
         if self.dist is not None:
             all_reduce_sum(red, self.dist)     # the one collective of a train step (RCCL over xGMI)
+            if self.stash:
+                all_reduce_sum(gB_f, self.dist)
+                all_reduce_sum(gB_b, self.dist)
 
         # ---- once-per-step adjoints and the chain through the positivity transforms
         grads = {}
         gvx = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
         gvy = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
-        for g, pack, slab, Do in (('f', self.pack_f, red[:sf], self.dim_x), ('b', self.pack_b, red[sf:sf + sb], self.dob)):
+        for g, pack, slab, Do, gBx in (('f', self.pack_f, red[:sf], self.dim_x, gB_f),
+                                       ('b', self.pack_b, red[sf:sf + sb], self.dob, gB_b)):
             gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(pack, slab, p[g + '.zeta_pos'], c[g + '.ls'], c[g + '.var'],
-                                                              p[g + '.zeta_mean'], c[g + '.zvar'], Do)
+                                                              p[g + '.zeta_mean'], c[g + '.zvar'], Do, gBx)
             grads[g + '.zeta_pos'] = gz
             grads[g + '.zeta_mean'] = gmu
             grads[g + '.zeta_var_unc'] = gs2 * torch.sigmoid(p[g + '.zeta_var_unc'])
@@ -199,7 +211,67 @@ class HipElboGrad:
                  'info': ws.out[7]}
         return -elbo, grads, terms
 
-    def _gp_adjoint(self, pack, slab, Z, ls, var, zmean, zvar, Do):
+    def _adjoint_stash(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):
+        """Stash-mode adjoint (M > 112): time-chunked launches, every launch followed by one float64 GEMM that
+        contracts the stashed A2bar / K tiles into d loss / d K^-1 (include/cbfssm_hip.h)."""
+        lib = _l.load()
+        st = _stream()
+        pb = C.byref(prob)
+        dev = self.device
+        f = dict(dtype=torch.float64, device=dev)
+        Mp = self.pack_f.layout.Mp
+        T, N = prob.T, prob.B * prob.S
+        groups = (N + 15) // 16
+        P = 2 * prob.recog_len
+        cols_max = max(groups * 16 * 2 * P, self.stash_bytes // (2 * Mp * 8))
+        if self._stash_buf is None or self._stash_buf[0].numel() < Mp * cols_max:
+            self._stash_buf = (torch.zeros(Mp * cols_max, **f), torch.zeros(Mp * cols_max, **f))
+        sa, sk = self._stash_buf
+        sf, sb = self.slab_f, self.slab_b
+        red[:sf + sb].zero_()
+        tmp = torch.zeros(max(sf, sb), **f)
+        gB_f = torch.zeros(Mp, Mp, **f)
+        gB_b = torch.zeros(Mp, Mp, **f)
+        # forward pass, backwards in time
+        per = max(1, cols_max // (groups * 16))
+        t_hi = T - 2
+        first = True
+        while t_hi >= 0 or first:
+            first = False
+            t_lo = max(0, t_hi - per + 1)
+            cols = groups * max(0, t_hi - t_lo + 1) * 16
+            rc = lib.cbfssm_forward_pass_bwd_ex_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
+                                                    _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
+                                                    _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), cL,
+                                                    _ptr(ws.gy2), _ptr(ws.gpart_f), t_hi, t_lo, _ptr(ws.gx_carry),
+                                                    _ptr(sa), _ptr(sk), cols, st)
+            _l.check(rc, 'cbfssm_forward_pass_bwd_ex_f64')
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp[:sf]), st), 'reduce f')
+            red[:sf] += tmp[:sf]
+            if cols:
+                gB_f.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
+            t_hi = t_lo - 1
+            if t_hi < 0:
+                break
+        # both backward runs, a range of resample-to-resample segments per launch
+        nseg = int(lib.cbfssm_bwd_segments(pb))
+        per = max(1, cols_max // (groups * 2 * P * 16))
+        seg0 = 0
+        while seg0 < nseg:
+            seg1 = min(nseg, seg0 + per)
+            cols = groups * 2 * (seg1 - seg0) * P * 16
+            rc = lib.cbfssm_backward_pass_bwd_ex_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
+                                                     _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
+                                                     _ptr(ws.h_all), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), seg0, seg1, 1,
+                                                     _ptr(sa), _ptr(sk), cols, st)
+            _l.check(rc, 'cbfssm_backward_pass_bwd_ex_f64')
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, 2 * groups, _ptr(tmp[:sb]), st), 'reduce b')
+            red[sf:sf + sb] += tmp[:sb]
+            gB_b.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
+            seg0 = seg1
+        return gB_f, gB_b
+
+    def _gp_adjoint(self, pack, slab, Z, ls, var, zmean, zvar, Do, gB_stash=None):
         """Adjoint of gp_prepare (K_mm -> chol -> K^-1, operand scaling, prior KL) given the reduced data slab."""
         lay = pack.layout
         M, D, NBLK, JB = self.M, self.D, lay.NBLK, lay.JB
@@ -208,8 +280,11 @@ class HipElboGrad:
         o += NBLK * 256
         gs2 = _unpack_c(slab[o:o + NBLK * 256], NBLK, 1)[:M, :Do]
         o += NBLK * 256
-        gB = _unpack_c(slab[o:o + NBLK * NBLK * 256], NBLK, NBLK)[:M, :M]
-        o += NBLK * NBLK * 256
+        if gB_stash is None:
+            gB = _unpack_c(slab[o:o + NBLK * NBLK * 256], NBLK, NBLK)[:M, :M]
+            o += NBLK * NBLK * 256
+        else:
+            gB = gB_stash[:M, :M]
         gZf = _unpack_c(slab[o:o + NBLK * JB * 256], NBLK, JB)
         o += NBLK * JB * 256
         small = slab[o:o + 128]

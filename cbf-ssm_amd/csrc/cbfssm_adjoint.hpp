@@ -83,26 +83,35 @@ struct RevArgs {
     double* gpart;         // [workgroup][slab]
     int64_t slab;          // doubles per workgroup
     int KSr;               // ceil(M / 4)
-    int nchunk;            // bwd: time chunks per run (grid.z), cut at resample boundaries
+    // time range of this launch
+    int t_hi, t_lo;        // fwd: steps t = t_hi .. t_lo (descending), t_hi <= T-2
+    int seg0, seg1;        // bwd: resample-to-resample segments [seg0, seg1) of each run, split over grid.z chunks
+    int nchunk;            // bwd: grid.z
+    double* gx_carry;      // fwd: (N, dim_x) adjoint of x_{t_lo} handed to the next launch (null: single launch)
+    // stash mode (tile heights whose K^-1-adjoint does not fit the VGPR file): A2bar and K tiles of every step go to
+    // HBM as [Mp][ld] matrices, column = (workgroup * chunk_steps + step) * 16 + chain; one GEMM per launch follows
+    double* stash_a;
+    double* stash_k;
+    int64_t stash_ld;
+    int chunk_steps;
 };
 
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
-template <int NBLK, int JB>
+template <int NBLK, int JB, bool STASH>
 struct Slab {
-    static constexpr int gMu = 0;                              // [NBLK][256]
-    static constexpr int gS2 = gMu + NBLK * 256;               // [NBLK][256]
-    static constexpr int gB = gS2 + NBLK * 256;                // [NBLK][NBLK][256]
-    static constexpr int gZ = gB + NBLK * NBLK * 256;          // [NBLK][JB][256]
-    static constexpr int small = gZ + NBLK * JB * 256;         // 128: [0,16) gvx, [16,32) gvy, [32,32+16*JB) glx, 96 gsig, 97 glogsig
-    static constexpr int total = small + 192;   // [128,192): diagnostic sub-phase stamps (CBF_REV_STAMPS builds only)
+    static constexpr int gMu = 0;                                         // [NBLK][256]
+    static constexpr int gS2 = gMu + NBLK * 256;                          // [NBLK][256]
+    static constexpr int gB = gS2 + NBLK * 256;                           // [NBLK][NBLK][256]  (absent in stash mode)
+    static constexpr int gZ = gB + (STASH ? 0 : NBLK * NBLK * 256);       // [NBLK][JB][256]
+    static constexpr int small = gZ + NBLK * JB * 256;   // [0,16) gvx, [16,32) gvy, [32,32+16*JB) glx, 96 gsig, 97 glogsig
+    static constexpr int total = small + 192;            // [100,192): diagnostic stamps (CBF_REV_STAMPS builds only)
 };
 
-// BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the
-// ceil(M/4) k-steps that carry data); otherwise it streams from L2.
-template <int NBLK, int DK, bool BLDS, int MODE>
-__global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
+// BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the ceil(M/4)
+// k-steps that carry data); otherwise it streams from L2.  RB: 16-row blocks of inducing points per wave.
+template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE>
+__global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArgs a)
 {
-    constexpr int RB = 1;
     constexpr bool BREG = false;
     typedef Tile<NBLK, RB, DK, BREG> TT;
     constexpr int W = TT::W, NT = TT::NT, MP = TT::MP, KS = TT::KS;
@@ -111,7 +120,8 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     constexpr int GPW = (NG + W - 1) / W;               // groups per wave in phase G
     constexpr int PD = 17;                              // padded row length of the LDS tiles
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
-    typedef Slab<NBLK, JB> SL;
+    constexpr int NCB = STASH ? 1 : NBLK;
+    typedef Slab<NBLK, JB, STASH> SL;
 
     extern __shared__ double lds[];
     double* xq = lds;                                   // [4*DK][17]
@@ -135,25 +145,31 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     const int run = (MODE == MODE_BWD) ? int(blockIdx.y) : 0;
     const int R = a.recog_len, P = 2 * R;
     const int KSr = a.KSr;                              // k-steps of K^-1 that carry data: ceil(M/4)
+    const int64_t wg_linear = (int64_t(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 
-    // ---- loop-invariant operands
+    // ---- loop-invariant operands (Z~ rows and cz of the owned row blocks stay in VGPRs; the small operand images
+    // muA/s2A/muB/s2B/ZT are re-read from L1/L2 where they are used: the VGPRs hold the adjoint accumulators)
     TT tile;
     tile.template load_operands<false>(a.pk, w, l);
-    // (the small operand images muA/s2A/muB/s2B/ZT are re-read from L1/L2 where they are used: the VGPRs are
-    //  needed for the K^-1-adjoint accumulator)
-    const double* muBp = a.rk.muB + w * 256 + l;
-    const double* s2Bp = a.rk.s2B + w * 256 + l;
-    const double* ZTp = a.rk.ZT + w * JB * 256 + l;
-    const double* muAp = a.pk.muA + w * 256 + l;
-    const double* s2Ap = a.pk.s2A + w * 256 + l;
+    bool ok[RB];
+    int rbs[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        ok[i] = (w * RB + i) < NBLK;
+        rbs[i] = ok[i] ? (w * RB + i) : (NBLK - 1);
+    }
 
-    // ---- accumulators of the parameter adjoints (whole pass)
-    d4 gMu = {0, 0, 0, 0}, gS2 = {0, 0, 0, 0};
-    d4 gB[NBLK], gZ[JB];
+    // ---- accumulators of the parameter adjoints (whole launch)
+    d4 gMu[RB], gS2[RB], gZ[RB][JB], gB[RB][NCB];
 #pragma unroll
-    for (int i = 0; i < NBLK; ++i) gB[i] = d4{0, 0, 0, 0};
+    for (int i = 0; i < RB; ++i) {
+        gMu[i] = d4{0, 0, 0, 0};
+        gS2[i] = d4{0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < JB; ++i) gZ[i] = d4{0, 0, 0, 0};
+        for (int j = 0; j < JB; ++j) gZ[i][j] = d4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) gB[i][j] = d4{0, 0, 0, 0};
+    }
 
     // ---- phase D/G lane state.  Phase D lanes: (d = 4q+g, chain nl), q = w + qi*W < 4.
     constexpr int QPW = TT::QPW;
@@ -194,33 +210,47 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     for (int i = tid; i < 4 * DK * PD; i += NT) xq[i] = 0.0;
     for (int i = tid; i < 16 * PD; i += NT) { Fm[i] = 0.0; Fv[i] = 0.0; }
     if (BLDS) {
-        for (int s = 0; s < KSr; ++s) Bl[(w * KSr + s) * 64 + l] = a.pk.Bp[(w * KS + s) * 64 + l];
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (ok[i])
+                for (int s = 0; s < KSr; ++s) Bl[(rbs[i] * KSr + s) * 64 + l] = a.pk.Bp[(rbs[i] * KS + s) * 64 + l];
     }
-    const double* bop = BLDS ? (Bl + w * KSr * 64 + l) : (a.pk.Bp + w * KS * 64 + l);
+    const double* bop[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) bop[i] = BLDS ? (Bl + rbs[i] * KSr * 64 + l) : (a.pk.Bp + rbs[i] * KS * 64 + l);
     __syncthreads();
 
-    // time range.  Backward runs: chunk z of run y covers whole resample-to-resample segments (the carried adjoint is
-    // zero at a segment start, cbfssm.py:133-136), so chunks are independent workgroups.
-    int t_begin = 0, nsteps = (MODE == MODE_FWD) ? (T - 1) : T;
-    if (MODE == MODE_BWD) {
+    // ---- time range.  Backward runs: chunk z of run y covers whole resample-to-resample segments (the carried
+    // adjoint is zero at a segment start, cbfssm.py:133-136), so chunks are independent workgroups.
+    int t_begin = 0, nsteps = 0;
+    if (MODE == MODE_FWD) {
+        nsteps = a.t_hi - a.t_lo + 1;
+        if (nsteps < 0) nsteps = 0;
+    } else {
         const int o = run * R;
-        const int nseg = (T + o) / P + 1;                    // segment k starts at max(0, P*k - o), k = 0..nseg-1
         const int z = blockIdx.z, nz = a.nchunk;
-        const int k0 = (z * nseg) / nz, k1 = ((z + 1) * nseg) / nz;
-        const int tb = (k0 == 0) ? 0 : min(T, P * k0 - o);
-        const int te = (k1 >= nseg) ? T : min(T, P * k1 - o);
+        const int nsg = a.seg1 - a.seg0;
+        const int k0 = a.seg0 + (z * nsg) / nz, k1 = a.seg0 + ((z + 1) * nsg) / nz;   // segment k starts at max(0, P*k - o)
+        const int tb = (k0 <= 0) ? 0 : min(T, P * k0 - o);
+        const int te = min(T, max(0, P * k1 - o));
         t_begin = tb;
         nsteps = max(0, te - tb);
     }
     if (MODE == MODE_FWD && nsteps > 0) {
-        // adjoint of x_{T-1}: only the log-likelihood sees it      (cbfssm.py:245-251)
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             const int d = 4 * (w + qi * W) + g;
-            if (act[qi] && d < a.dim_y) {
-                const double xv = a.x[(int64_t(T - 1) * N + c) * a.dim_x + d];
-                const double yv = a.y[(int64_t(bq) * T + (T - 1)) * a.dim_y + d];
-                gcar[qi] = -a.cL * (yv - xv) / vy[qi];
+            if (act[qi]) {
+                if (a.t_hi == T - 2) {
+                    // adjoint of x_{T-1}: only the log-likelihood sees it      (cbfssm.py:245-251)
+                    if (d < a.dim_y) {
+                        const double xv = a.x[(int64_t(T - 1) * N + c) * a.dim_x + d];
+                        const double yv = a.y[(int64_t(bq) * T + (T - 1)) * a.dim_y + d];
+                        gcar[qi] = -a.cL * (yv - xv) / vy[qi];
+                    }
+                } else {
+                    gcar[qi] = a.gx_carry[int64_t(c) * a.dim_x + d];      // from the launch that handled t_hi + 1
+                }
             }
         }
     }
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
     CBF_STAMP_DECL;
     CBF_STAMP_START();
     for (int step = 0; step < nsteps; ++step) {
-        const int t = (MODE == MODE_FWD) ? (T - 2 - step) : (t_begin + step);
+        const int t = (MODE == MODE_FWD) ? (a.t_hi - step) : (t_begin + step);
 
         // ---- A: GP input of step t from the saved trajectory
         double hcur[QPW];
@@ -285,47 +315,69 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         }
         xx += __shfl_xor(xx, 16);
         xx += __shfl_xor(xx, 32);
-        d4 kreg;
-        {
-            d4 e;
+        d4 kreg[RB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = tile.czr[0][r] - 0.5 * xx;
+        for (int i = 0; i < RB; ++i) {
+            kreg[i] = d4{0, 0, 0, 0};
+            if (ok[i]) {
+                d4 e;
 #pragma unroll
-            for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[0][s], bx[s], e);
+                for (int r = 0; r < 4; ++r) e[r] = tile.czr[i][r] - 0.5 * xx;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                kreg[r] = exp(e[r]);
-                Kt[(16 * w + 4 * r + g) * PD + nl] = kreg[r];
+                for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[i][s], bx[s], e);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    kreg[i][r] = exp(e[r]);
+                    Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
+                }
             }
         }
         CBF_STAMP_BARRIER(1);
 
         // ---- C: A2 rows of this wave, P1/P2
         CBF_STAMP_MARK0();
-        double mA[4], sA[4];      // epilogue operands: fetched now, used after the K^-1 K loop
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { mA[r] = muAp[r * 64]; sA[r] = s2Ap[r * 64]; }
-        d4 a2;
+        d4 a2[RB];
         {
-            d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            d4 acc[RB][2];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
             int s = 0;
 #pragma unroll 2
             for (; s + 1 < KSr; s += 2) {
-                acc0 = CBF_MFMA(bop[s * 64], Kt[(4 * s + g) * PD + nl], acc0);
-                acc1 = CBF_MFMA(bop[(s + 1) * 64], Kt[(4 * s + 4 + g) * PD + nl], acc1);
+                const double b0 = Kt[(4 * s + g) * PD + nl], b1 = Kt[(4 * s + 4 + g) * PD + nl];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    if (ok[i]) {
+                        acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                        acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
+                    }
+                }
             }
-            if (s < KSr) acc0 = CBF_MFMA(bop[s * 64], Kt[(4 * s + g) * PD + nl], acc0);
-            a2 = acc0 + acc1;
+            if (s < KSr) {
+                const double b0 = Kt[(4 * s + g) * PD + nl];
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) a2[i] = acc[i][0] + acc[i][1];
         }
         CBF_STAMP_MARK(0);
         {
             d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
             double q = 0.0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                P1 = CBF_MFMA(mA[r], a2[r], P1);
-                P2 = CBF_MFMA(sA[r], a2[r] * a2[r], P2);
-                q = fma(kreg[r], a2[r], q);
+            for (int i = 0; i < RB; ++i) {
+                if (ok[i]) {
+                    const double* mAp = a.pk.muA + rbs[i] * 256 + l;
+                    const double* sAp = a.pk.s2A + rbs[i] * 256 + l;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        P1 = CBF_MFMA(mAp[r * 64], a2[i][r], P1);
+                        P2 = CBF_MFMA(sAp[r * 64], a2[i][r] * a2[i][r], P2);
+                        q = fma(kreg[i][r], a2[i][r], q);
+                    }
+                }
             }
             q += __shfl_xor(q, 16);
             q += __shfl_xor(q, 32);
@@ -335,9 +387,6 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
                 part[w * PSL + (1 * 4 + r) * 64 + l] = P2[r] - q;
             }
         }
-        double mB[4], sB[4];      // operands of phase E: fetched now, they land while phase D runs
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { mB[s] = muBp[s * 64]; sB[s] = s2Bp[s * 64]; }
         CBF_STAMP_MARK(1);
         CBF_STAMP_BARRIER(2);
 
@@ -430,49 +479,66 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         }
         fvsum += __shfl_xor(fvsum, 16);
         fvsum += __shfl_xor(fvsum, 32);
-        d4 a2bar;
-        {
-            d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                T1 = CBF_MFMA(mB[s], fmB[s], T1);
-                T2 = CBF_MFMA(sB[s], fvB[s], T2);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a2bar[r] = T1[r] + 2.0 * a2[r] * T2[r] - kreg[r] * fvsum;
-        }
-        CBF_STAMP_MARK(2);
-        // 16x16 transposes through this wave's own rows of the A2bar tile (nobody else reads them before the next
-        // barrier): C-layout (row g+4r, col nl) -> A-operand layout (row nl, k = 4s+g)
-        double a2T[4], abT[4];
-        double* own = A2t + 16 * w * PD;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) own[(g + 4 * r) * PD + nl] = a2[r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) a2T[s] = own[nl * PD + 4 * s + g];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) own[(g + 4 * r) * PD + nl] = a2bar[r];      // stays: the A2bar tile of phase F
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) abT[s] = own[nl * PD + 4 * s + g];
-        CBF_STAMP_MARK(3);
+        double fmT[4], fvT[4];      // the same tiles with the chain index as k: [n = 4s+g][col = nl]
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // B operands with the chain index as k: [n = 4s+g][col = nl]
-            const double fmT = Fm[nl * PD + 4 * s + g];
-            const double fvT = Fv[nl * PD + 4 * s + g];
-            gMu = CBF_MFMA(a2T[s], fmT, gMu);                       // mubar[m][d]  += A2[m][n] Fm[d][n]
-            gS2 = CBF_MFMA(a2T[s] * a2T[s], fvT, gS2);              // s2bar[m][d]  += A2[m][n]^2 Fv[d][n]
+            fmT[s] = Fm[nl * PD + 4 * s + g];
+            fvT[s] = Fv[nl * PD + 4 * s + g];
         }
-        CBF_STAMP_MARK(4);
+        d4 a2bar[RB];
 #pragma unroll
-        for (int cb = 0; cb < NBLK; ++cb) {
+        for (int i = 0; i < RB; ++i) {
+            a2bar[i] = d4{0, 0, 0, 0};
+            if (ok[i]) {
+                const double* mBp = a.rk.muB + rbs[i] * 256 + l;
+                const double* sBp = a.rk.s2B + rbs[i] * 256 + l;
+                d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double kT = Kt[(16 * cb + nl) * PD + 4 * s + g];
-                gB[cb] = CBF_MFMA(abT[s], kT, gB[cb]);              // Kinvbar[m'][m] += A2bar[m'][n] K[m][n]
+                for (int s = 0; s < 4; ++s) {
+                    T1 = CBF_MFMA(mBp[s * 64], fmB[s], T1);
+                    T2 = CBF_MFMA(sBp[s * 64], fvB[s], T2);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a2bar[i][r] = T1[r] + 2.0 * a2[i][r] * T2[r] - kreg[i][r] * fvsum;
+                // 16x16 transposes through this wave's own rows of the A2bar tile (nobody else reads them before the
+                // next barrier): C-layout (row g+4r, col nl) -> A-operand layout (row nl, k = 4s+g)
+                double a2T[4], abT[4];
+                double* own = A2t + 16 * rbs[i] * PD;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) own[(g + 4 * r) * PD + nl] = a2[i][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a2T[s] = own[nl * PD + 4 * s + g];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) own[(g + 4 * r) * PD + nl] = a2bar[i][r];   // stays: A2bar tile of phase F
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    gMu[i] = CBF_MFMA(a2T[s], fmT[s], gMu[i]);                  // mubar[m][d] += A2[m][n] Fm[d][n]
+                    gS2[i] = CBF_MFMA(a2T[s] * a2T[s], fvT[s], gS2[i]);         // s2bar[m][d] += A2[m][n]^2 Fv[d][n]
+                }
+                if constexpr (STASH) {
+                    // A2bar and K rows of this block, column = (workgroup, step, chain)
+                    const int64_t col = (wg_linear * a.chunk_steps + step) * 16 + nl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = 16 * rbs[i] + g + 4 * r;
+                        a.stash_a[row * a.stash_ld + col] = a2bar[i][r];
+                        a.stash_k[row * a.stash_ld + col] = kreg[i][r];
+                    }
+                } else {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) abT[s] = own[nl * PD + 4 * s + g];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const double kT = Kt[(16 * cb + nl) * PD + 4 * s + g];
+                            gB[i][cb] = CBF_MFMA(abT[s], kT, gB[i][cb]);        // Kinvbar[m'][m] += A2bar[m'][n] K[m][n]
+                        }
+                    }
+                }
             }
         }
         CBF_STAMP_MARK(5);
@@ -480,49 +546,77 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
 
         // ---- F: Kbar, Ebar, input adjoint partials, Zbar~
         CBF_STAMP_MARK0();
-        double zT[JB][4];
-#pragma unroll
-        for (int jb = 0; jb < JB; ++jb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) zT[jb][r] = ZTp[(jb * 4 + r) * 64];
-        d4 ebar;
+        d4 ebar[RB];
         {
-            d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            d4 acc[RB][2];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
             int s = 0;
 #pragma unroll 2
             for (; s + 1 < KSr; s += 2) {
-                acc0 = CBF_MFMA(bop[s * 64], A2t[(4 * s + g) * PD + nl], acc0);
-                acc1 = CBF_MFMA(bop[(s + 1) * 64], A2t[(4 * s + 4 + g) * PD + nl], acc1);
-            }
-            if (s < KSr) acc0 = CBF_MFMA(bop[s * 64], A2t[(4 * s + g) * PD + nl], acc0);
+                const double b0 = A2t[(4 * s + g) * PD + nl], b1 = A2t[(4 * s + 4 + g) * PD + nl];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ebar[r] = (acc0[r] + acc1[r] - a2[r] * fvsum) * kreg[r];
+                for (int i = 0; i < RB; ++i) {
+                    if (ok[i]) {
+                        acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                        acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
+                    }
+                }
+            }
+            if (s < KSr) {
+                const double b0 = A2t[(4 * s + g) * PD + nl];
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ebar[i][r] = (acc[i][0][r] + acc[i][1][r] - a2[i][r] * fvsum) * kreg[i][r];
         }
         CBF_STAMP_MARK(6);
+        {
+            d4 xp[JB];
 #pragma unroll
-        for (int jb = 0; jb < JB; ++jb) {
-            d4 xp = {0, 0, 0, 0};
+            for (int jb = 0; jb < JB; ++jb) xp[jb] = d4{0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xp = CBF_MFMA(zT[jb][r], ebar[r], xp);   // rows j, k = m of this wave
+            for (int i = 0; i < RB; ++i) {
+                if (ok[i]) {
+                    const double* ZTp = a.rk.ZT + rbs[i] * JB * 256 + l;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[r];
+                    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            xp[jb] = CBF_MFMA(ZTp[(jb * 4 + r) * 64], ebar[i][r], xp[jb]);   // rows j, k = m of this block
+                }
+            }
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
         }
         CBF_STAMP_MARK(7);
-        double ebT[4];
-        double* ownk = Kt + 16 * w * PD;     // the K tile is dead after phase E: reuse this wave's rows for Ebar^T
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ownk[(g + 4 * r) * PD + nl] = ebar[r];
-        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < RB; ++i) {
+            if (ok[i]) {
+                double ebT[4];
+                double* ownk = Kt + 16 * rbs[i] * PD;   // the K tile is dead after phase E: reuse own rows for Ebar^T
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ebT[s] = ownk[nl * PD + 4 * s + g];
+                for (int r = 0; r < 4; ++r) ownk[(g + 4 * r) * PD + nl] = ebar[i][r];
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int jb = 0; jb < JB; ++jb) {
-            const int j = 16 * jb + nl;
+                for (int s = 0; s < 4; ++s) ebT[s] = ownk[nl * PD + 4 * s + g];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double xT = (j < 4 * DK) ? xq[j * PD + 4 * s + g] : 0.0;
-                if (j == D) xT = 1.0;                                             // ones column: row sums of Ebar
-                gZ[jb] = CBF_MFMA(ebT[s], xT, gZ[jb]);                            // Zbar~[m][j] += Ebar[m][n] x~[j][n]
+                for (int jb = 0; jb < JB; ++jb) {
+                    const int j = 16 * jb + nl;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        double xT = (j < 4 * DK) ? xq[j * PD + 4 * s + g] : 0.0;
+                        if (j == D) xT = 1.0;                                         // ones column: row sums of Ebar
+                        gZ[i][jb] = CBF_MFMA(ebT[s], xT, gZ[i][jb]);                  // Zbar~[m][j] += Ebar[m][n] x~[j][n]
+                    }
+                }
             }
         }
         CBF_STAMP_MARK(8);
@@ -581,28 +675,62 @@ __global__ __launch_bounds__(64 * NBLK) void rev_kernel(RevArgs a)
         CBF_STAMP_BARRIER(6);
     }
 
-    if (MODE == MODE_FWD && nsteps == 0) {
-        // T == 1: x_0 = y_tilde_0 only feeds the log-likelihood through its observed dims -> no gradient to y2
+    if (MODE == MODE_FWD) {
+        if (nsteps == 0 && a.t_hi < 0) {
+            // T == 1: x_0 = y_tilde_0 only feeds the log-likelihood through its observed dims -> no gradient to y2
 #pragma unroll
-        for (int qi = 0; qi < QPW; ++qi) {
-            const int d = 4 * (w + qi * W) + g;
-            if (act[qi] && cvalid && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = 0.0;
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int d = 4 * (w + qi * W) + g;
+                if (act[qi] && cvalid && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = 0.0;
+            }
+        }
+        if (a.gx_carry && a.t_lo > 0 && nsteps > 0) {
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int d = 4 * (w + qi * W) + g;
+                if (act[qi] && cvalid) a.gx_carry[int64_t(c) * a.dim_x + d] = gcar[qi];
+            }
+        }
+    }
+    if constexpr (STASH) {
+        // unused step slots of this workgroup's column range must read as zero in the GEMM
+        for (int step = nsteps; step < a.chunk_steps; ++step) {
+            const int64_t col = (wg_linear * a.chunk_steps + step) * 16 + nl;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                if (ok[i]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = 16 * rbs[i] + g + 4 * r;
+                        a.stash_a[row * a.stash_ld + col] = 0.0;
+                        a.stash_k[row * a.stash_ld + col] = 0.0;
+                    }
+                }
+            }
         }
     }
 
     // ---- write this workgroup's slab
-    double* slab = a.gpart + ((int64_t(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * a.slab;
+    double* slab = a.gpart + wg_linear * a.slab;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        slab[SL::gMu + w * 256 + r * 64 + l] = gMu[r];
-        slab[SL::gS2 + w * 256 + r * 64 + l] = gS2[r];
+    for (int i = 0; i < RB; ++i) {
+        if (ok[i]) {
+            const int rb = rbs[i];
 #pragma unroll
-        for (int cb = 0; cb < NBLK; ++cb) slab[SL::gB + (w * NBLK + cb) * 256 + r * 64 + l] = gB[cb][r];
+            for (int r = 0; r < 4; ++r) {
+                slab[SL::gMu + rb * 256 + r * 64 + l] = gMu[i][r];
+                slab[SL::gS2 + rb * 256 + r * 64 + l] = gS2[i][r];
+                if constexpr (!STASH) {
 #pragma unroll
-        for (int jb = 0; jb < JB; ++jb) slab[SL::gZ + (w * JB + jb) * 256 + r * 64 + l] = gZ[jb][r];
+                    for (int cb = 0; cb < NCB; ++cb) slab[SL::gB + (rb * NBLK + cb) * 256 + r * 64 + l] = gB[i][cb][r];
+                }
+#pragma unroll
+                for (int jb = 0; jb < JB; ++jb) slab[SL::gZ + (rb * JB + jb) * 256 + r * 64 + l] = gZ[i][jb][r];
+            }
+        }
     }
     // small per-dimension sums: reduce over the 16 chains of each 16-lane group, lane nl == 0 writes
-    for (int i = tid; i < 128; i += NT) slab[SL::small + i] = 0.0;
+    for (int i = tid; i < 192; i += NT) slab[SL::small + i] = 0.0;
     __syncthreads();
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {

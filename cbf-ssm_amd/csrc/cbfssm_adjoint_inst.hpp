@@ -1,38 +1,49 @@
-// Per-NBLK instantiation of the adjoint kernels (tile heights whose K^-1-adjoint accumulator fits the VGPR file).
+// Per-NBLK instantiation of the adjoint kernels.
 #pragma once
 #include "cbfssm_adjoint.hpp"
 #include "cbfssm_inst.hpp"
 
 namespace cbfssm {
 
+// NBLK <= 7 (M <= 112): one row block per wave, the K^-1-adjoint accumulator (NBLK x 16 x 16 f64 per wave) stays in
+// VGPRs for the whole pass.  Larger tiles: two row blocks per wave and the accumulator does not fit the register file
+// of a CU any more -- the A2bar / K tiles of every step are stashed in HBM and contracted by one GEMM per launch.
+template <int NBLK>
+struct RevCfg {
+    static constexpr bool STASH = (NBLK > 7);
+    static constexpr int RB = STASH ? 2 : 1;
+    static constexpr int W = (NBLK + RB - 1) / RB;
+};
+
 template <int NBLK, int DK>
 struct RevGeom {
+    typedef RevCfg<NBLK> C;
     static constexpr int JB = (4 * DK + 1 + 15) / 16;
     static constexpr int PSL = (JB > 2 ? JB : 2) * 256;
-    static constexpr int LDS_BASE = 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + NBLK * PSL + 64;
+    static constexpr int LDS_BASE = 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + C::W * PSL + 64;
     static constexpr int LDS_LIMIT = 163840 / 8;
-    static constexpr int SLAB = Slab<NBLK, JB>::total;
+    static constexpr int SLAB = Slab<NBLK, JB, C::STASH>::total;
 };
 
 template <int NBLK, int DK, int MODE>
 int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
 {
-    // K^-1 image in LDS when it fits next to the tiles (M <= 104 at NBLK = 7), else streamed from L2; the VGPRs hold
-    // the K^-1-adjoint accumulator either way
+    // K^-1 image in LDS when it fits next to the tiles (M <= 104 at NBLK = 7), else streamed from L2
     typedef RevGeom<NBLK, DK> G;
+    typedef RevCfg<NBLK> C;
     const int blds_doubles = NBLK * a.KSr * 64;
     if (G::LDS_BASE + blds_doubles <= G::LDS_LIMIT) {
         const size_t lds = size_t(G::LDS_BASE + blds_doubles) * sizeof(double);
-        auto k = rev_kernel<NBLK, DK, true, MODE>;
+        auto k = rev_kernel<NBLK, C::RB, DK, true, C::STASH, MODE>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(64 * NBLK), lds, st, a);
+        hipLaunchKernelGGL(k, grid, dim3(64 * C::W), lds, st, a);
     } else {
         const size_t lds = size_t(G::LDS_BASE) * sizeof(double);
-        auto k = rev_kernel<NBLK, DK, false, MODE>;
+        auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(64 * NBLK), lds, st, a);
+        hipLaunchKernelGGL(k, grid, dim3(64 * C::W), lds, st, a);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
@@ -85,5 +96,4 @@ int64_t rev_slab_n(int DK)
     int64_t rev_slab_nb##NB(int DK) { return rev_slab_n<NB>(DK); }                               \
     }
 
-// tile heights with an adjoint kernel (M <= 112 this round; larger M needs the K^-1-adjoint accumulator outside VGPRs)
-#define CBF_FOR_EACH_REV_NBLK(X) X(1) X(2) X(4) X(7)
+#define CBF_FOR_EACH_REV_NBLK(X) X(1) X(2) X(4) X(7) X(10) X(13) X(16) X(20)

@@ -443,6 +443,7 @@ int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out)
     out->s2B = take(int64_t(nblk) * 256);
     out->ZT = take(int64_t(nblk) * out->JB * 256);
     out->rev_slab = rev_slab(nblk, dk);
+    out->rev_stash = (nblk > 7) ? 1 : 0;
     out->work = take(M > PREP_LDS_MAX_M ? int64_t(M) * (M | 1) : 0);
     out->total = o;
     return 0;
@@ -622,10 +623,22 @@ static int rev_chunks(const cbfssm_problem* p)
     return int(c);
 }
 
+static int bwd_total_segments(const cbfssm_problem* p)
+{
+    // segment k of run r starts at max(0, 2R*k - r*R); run 1 has the most: floor((T-1+R)/2R) + 1
+    return (p->T - 1 + p->recog_len) / (2 * p->recog_len) + 1;
+}
+
 int64_t cbfssm_rev_workgroups(const cbfssm_problem* p, int backward_runs)
 {
     if (!p || p->recog_len < 1) return -1;
     return (int64_t(p->B) * p->S + 15) / 16 * (backward_runs ? 2 * rev_chunks(p) : 1);
+}
+
+int cbfssm_bwd_segments(const cbfssm_problem* p)
+{
+    if (!p || p->recog_len < 1) return -1;
+    return bwd_total_segments(p);
 }
 
 static int fill_rev(RevArgs& a, const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack, int Do)
@@ -638,9 +651,46 @@ static int fill_rev(RevArgs& a, const cbfssm_problem* p, const cbfssm_pack_layou
     a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = p->k_factor;
     a.slab = L->rev_slab;
     a.KSr = (L->M + 3) / 4;
-    if (L->rev_slab <= 0)
-        return fail(-3, "no adjoint kernel for M=%d (tile height %d): training supports M <= 112 in this build",
-                    L->M, L->NBLK);
+    if (L->rev_slab <= 0) return fail(-3, "no adjoint kernel for M=%d (tile height %d)", L->M, L->NBLK);
+    return 0;
+}
+
+static int set_stash(RevArgs& a, const cbfssm_pack_layout* L, double* stash_a, double* stash_k, int64_t stash_ld,
+                     int64_t nwg, int chunk_steps)
+{
+    if (L->rev_stash) {
+        if (!stash_a || !stash_k) return fail(-1, "this tile height (M=%d) needs stash buffers", L->M);
+        if (stash_ld < nwg * chunk_steps * 16) return fail(-1, "stash_ld too small: need %lld", (long long)(nwg * chunk_steps * 16));
+        a.stash_a = stash_a; a.stash_k = stash_k; a.stash_ld = stash_ld; a.chunk_steps = chunk_steps;
+    }
+    return 0;
+}
+
+int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                                   const double* var_x, const double* var_y, const double* u, const double* y,
+                                   const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
+                                   double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
+                                   double* stash_k, int64_t stash_ld, void* stream)
+{
+    int rc = check_problem(p, L, p ? p->dim_x : 0);
+    if (rc) return rc;
+    if (!pack_f || !var_x || !var_y || !u || !y || !x || !gpart) return fail(-1, "null pointer");
+    if (p->dim_x > p->dim_y && (!y2 || !gy2)) return fail(-1, "y2/gy2 is null");
+    if (p->T > 1 && !eps_f) return fail(-1, "eps_f is null");
+    if (t_hi > p->T - 2 || t_lo < 0) return fail(-1, "bad step range [%d, %d]", t_lo, t_hi);
+    if ((t_hi < p->T - 2 || t_lo > 0) && t_hi >= t_lo && !gx_carry) return fail(-1, "partial range needs gx_carry");
+    RevArgs a;
+    rc = fill_rev(a, p, L, pack_f, p->dim_x);
+    if (rc) return rc;
+    a.cL = cL; a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.x = x; a.y2 = y2; a.gy2 = gy2;
+    a.gpart = gpart; a.t_hi = t_hi; a.t_lo = t_lo; a.gx_carry = gx_carry;
+    const int64_t groups = (a.N + 15) / 16;
+    const int steps = t_hi >= t_lo ? t_hi - t_lo + 1 : 0;
+    rc = set_stash(a, L, stash_a, stash_k, stash_ld, groups, steps);
+    if (rc) return rc;
+    dim3 grid(unsigned(groups), 1);
+    rc = dispatch_rev(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
+    if (rc) return fail(rc, "forward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
 }
 
@@ -649,19 +699,35 @@ int cbfssm_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layou
                                 const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
                                 double* gpart, void* stream)
 {
-    int rc = check_problem(p, L, p ? p->dim_x : 0);
+    if (L && L->rev_stash) return fail(-3, "M=%d runs in stash mode: use cbfssm_forward_pass_bwd_ex_f64", L->M);
+    return cbfssm_forward_pass_bwd_ex_f64(p, L, pack_f, var_x, var_y, u, y, y2, eps_f, x, cL, gy2, gpart,
+                                          p ? p->T - 2 : -1, 0, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_b,
+                                    const double* var_x, const double* u, const double* y, const double* hid_b,
+                                    const double* eps_b, const double* h_all, const double* gy2, double cE,
+                                    double* gpart, int seg0, int seg1, int nchunk, double* stash_a, double* stash_k,
+                                    int64_t stash_ld, void* stream)
+{
+    int rc = check_problem(p, L, p ? p->dim_x - p->dim_y : 0);
     if (rc) return rc;
-    if (!pack_f || !var_x || !var_y || !u || !y || !x || !gpart) return fail(-1, "null pointer");
-    if (p->dim_x > p->dim_y && (!y2 || !gy2)) return fail(-1, "y2/gy2 is null");
-    if (p->T > 1 && !eps_f) return fail(-1, "eps_f is null");
+    if (!pack_b || !var_x || !u || !y || !hid_b || !eps_b || !h_all || !gy2 || !gpart) return fail(-1, "null pointer");
+    if (seg0 < 0 || seg1 <= seg0 || seg1 > bwd_total_segments(p) || nchunk < 1 || nchunk > seg1 - seg0)
+        return fail(-1, "bad segment range [%d, %d) / chunks %d", seg0, seg1, nchunk);
     RevArgs a;
-    rc = fill_rev(a, p, L, pack_f, p->dim_x);
+    rc = fill_rev(a, p, L, pack_b, p->dim_x - p->dim_y);
     if (rc) return rc;
-    a.cL = cL; a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.x = x; a.y2 = y2; a.gy2 = gy2;
-    a.gpart = gpart;
-    dim3 grid(unsigned((a.N + 15) / 16), 1);
-    rc = dispatch_rev(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
-    if (rc) return fail(rc, "forward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
+    a.cE = cE; a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.h_all = h_all;
+    a.gy2 = const_cast<double*>(gy2); a.gpart = gpart;
+    a.seg0 = seg0; a.seg1 = seg1; a.nchunk = nchunk;
+    const int64_t groups = (a.N + 15) / 16;
+    const int per = (seg1 - seg0 + nchunk - 1) / nchunk;
+    rc = set_stash(a, L, stash_a, stash_k, stash_ld, groups * 2 * nchunk, per * 2 * p->recog_len);
+    if (rc) return rc;
+    dim3 grid(unsigned(groups), 2, unsigned(nchunk));
+    rc = dispatch_rev(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
+    if (rc) return fail(rc, "backward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
 }
 
@@ -670,19 +736,10 @@ int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layo
                                  const double* eps_b, const double* h_all, const double* gy2, double cE,
                                  double* gpart, void* stream)
 {
-    int rc = check_problem(p, L, p ? p->dim_x - p->dim_y : 0);
-    if (rc) return rc;
-    if (!pack_b || !var_x || !u || !y || !hid_b || !eps_b || !h_all || !gy2 || !gpart) return fail(-1, "null pointer");
-    RevArgs a;
-    rc = fill_rev(a, p, L, pack_b, p->dim_x - p->dim_y);
-    if (rc) return rc;
-    a.cE = cE; a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.h_all = h_all;
-    a.gy2 = const_cast<double*>(gy2); a.gpart = gpart;
-    a.nchunk = rev_chunks(p);
-    dim3 grid(unsigned((a.N + 15) / 16), 2, unsigned(a.nchunk));
-    rc = dispatch_rev(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
-    if (rc) return fail(rc, "backward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
-    return 0;
+    if (L && L->rev_stash) return fail(-3, "M=%d runs in stash mode: use cbfssm_backward_pass_bwd_ex_f64", L->M);
+    if (!p || p->recog_len < 1) return fail(-1, "null problem");
+    return cbfssm_backward_pass_bwd_ex_f64(p, L, pack_b, var_x, u, y, hid_b, eps_b, h_all, gy2, cE, gpart, 0,
+                                           bwd_total_segments(p), rev_chunks(p), nullptr, nullptr, 0, stream);
 }
 
 int cbfssm_reduce_partials_f64(const double* gpart, int64_t slab, int64_t nwg, double* out, void* stream)

@@ -1,0 +1,2 @@
+#include "cbfssm_adjoint_inst.hpp"
+CBF_REV_INSTANTIATE(16)

@@ -57,7 +57,7 @@ typedef struct {
     int64_t ZT;       /* [NBLK][JB][4][64] (Z/lengthscale)^T as A-operand image A[row j][k = m]; row D = ones        */
     int64_t rev_slab; /* doubles of one adjoint partial slab (0: no adjoint kernel for this tile height)            */
     int64_t work;     /* [M][M|1]        factorisation workspace when M is too large for LDS                        */
-    int32_t M, D, Do, NBLK, DK, Mp, Dp, KS, JB, pad_;
+    int32_t M, D, Do, NBLK, DK, Mp, Dp, KS, JB, rev_stash;   /* rev_stash: 1 = adjoint runs in stash mode (M > 112) */
 } cbfssm_pack_layout;
 
 /* Problem description shared by the pass kernels (host struct, passed by pointer). */
@@ -190,6 +190,31 @@ int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layo
                                  const double* var_x, const double* u, const double* y, const double* hid_b,
                                  const double* eps_b, const double* h_all, const double* gy2, double cE,
                                  double* gpart, void* stream);
+
+/*
+ * General forms of the two adjoint passes: a time range per launch, and "stash mode" for tile heights whose
+ * K^-1-adjoint accumulator does not fit the VGPR file (layout->rev_stash == 1, M > 112; the slab then has no
+ * d/dK^-1 block).  In stash mode every step writes its A2bar and K tiles to stash_a / stash_k, two [Mp][stash_ld]
+ * row-major matrices with column = (workgroup * steps_per_workgroup + step) * 16 + chain, and the caller contracts
+ * them afterwards: d loss / d K^-1 += stash_a[:, :cols] @ stash_k[:, :cols]^T  (one plain library GEMM per launch).
+ *   forward:  steps t = t_hi .. t_lo (descending; full pass: T-2 .. 0).  A launch that does not start at T-2 reads the
+ *             adjoint of x_{t_hi+1} from gx_carry (N,dim_x); a launch that does not end at 0 writes it there.
+ *             columns used: groups * (t_hi - t_lo + 1) * 16.
+ *   backward: resample-to-resample segments [seg0, seg1) of both runs (cbfssm_bwd_segments(p) in total), split over
+ *             nchunk independent workgroup sets (grid.z).  gpart: groups * 2 * nchunk slabs.
+ *             columns used: groups * 2 * nchunk * ceil((seg1-seg0)/nchunk) * 2*recog_len * 16.
+ */
+int cbfssm_bwd_segments(const cbfssm_problem* p);
+int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
+                                   const double* var_x, const double* var_y, const double* u, const double* y,
+                                   const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
+                                   double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
+                                   double* stash_k, int64_t stash_ld, void* stream);
+int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const double* pack_b,
+                                    const double* var_x, const double* u, const double* y, const double* hid_b,
+                                    const double* eps_b, const double* h_all, const double* gy2, double cE,
+                                    double* gpart, int seg0, int seg1, int nchunk, double* stash_a, double* stash_k,
+                                    int64_t stash_ld, void* stream);
 
 /* out[i] = sum over the nwg slabs, in slab order (bitwise reproducible). */
 int cbfssm_reduce_partials_f64(const double* gpart, int64_t slab, int64_t nwg, double* out, void* stream);

@@ -77,3 +77,29 @@ def test_train_step_decreases_loss_and_matches_tf_adam_rule():
         assert torch.allclose(step.params[k], expect, rtol=0, atol=1e-12), k
     losses = [l0] + [float(step.step(u, y, noise)) for _ in range(10)]
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize('kw,gib', [
+    (dict(M=130, dim_x=9, dim_u=3, dim_y=2, T=14, B=2, S=9, recog_len=3, k_factor=20.), 4.0),       # tile height 10
+    (dict(M=200, dim_x=14, dim_u=7, dim_y=7, T=11, B=1, S=20, recog_len=2, k_factor=50., var_y=0.05 ** 2), 4.0),   # C4 tile
+    (dict(M=200, dim_x=14, dim_u=7, dim_y=7, T=11, B=1, S=20, recog_len=2, k_factor=50., var_y=0.05 ** 2), 3e-4),  # many launches
+    (dict(M=250, dim_x=4, dim_u=2, dim_y=2, T=9, B=2, S=9, recog_len=50, k_factor=1.), 4.0),        # tile height 16, T < R
+    (dict(M=300, dim_x=4, dim_u=2, dim_y=2, T=12, B=1, S=17, recog_len=2, k_factor=1.), 2e-4),      # C5 tile, chunked
+])
+def test_grad_stash_mode_matches_oracle(kw, gib):
+    """M > 112: the K^-1-adjoint is contracted from stashed tiles by GEMMs, in several time chunks when the stash
+    budget is small (gx_carry hand-off between launches)."""
+    from oracle import cbfssm_torch_ref as tref
+    w = syn.tiny(loss_factors=(2., 0.4), **kw)
+    cfg = w.model_config()
+    cfg['adjoint_stash_gib'] = gib
+    p = syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)
+    u, y = syn.make_inputs(w)
+    noise = syn.make_noise(w)
+    eng = train.HipElboGrad(cfg, DEV)
+    assert eng.stash
+    params = {k: torch.tensor(v, device=DEV) for k, v in p.items()}
+    loss, grads, _ = eng.loss_and_grads(params, u, y, noise)
+    scal, gref = tref.loss_and_grads(cfg, p, u, y, noise, True)
+    assert float(loss) == pytest.approx(scal['loss'], rel=1e-9)
+    _check(grads, gref)
