@@ -123,8 +123,8 @@ class HipElboGrad:
             if self.stash:
                 n_b = 2 * n_f          # one launch per segment range, grid.z = 1
                 ws.gx_carry = torch.zeros(prob.B * prob.S, prob.dim_x, **f)
-            ws.gpart_f = torch.zeros(n_f * self.slab_f, **f)
-            ws.gpart_b = torch.zeros(n_b * self.slab_b, **f)
+            ws.gpart_f = torch.zeros((n_f + 32) * self.slab_f, **f)      # + CBFSSM_REDUCE_SPLIT scratch slabs
+            ws.gpart_b = torch.zeros((n_b + 32) * self.slab_b, **f)
             ws.n_f, ws.n_b = n_f, n_b
             self._ws[key] = ws
         return self._ws[key]

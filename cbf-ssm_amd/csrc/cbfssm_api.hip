@@ -320,7 +320,31 @@ __global__ __launch_bounds__(1024) void combine_kernel(CombineArgs a)
     }
 }
 
-// Sum the per-workgroup slabs in a fixed order: out[i] = sum_wg gpart[wg][i].
+// Sum the per-workgroup slabs in a fixed order: out[i] = sum_wg gpart[wg][i].  Two stages (RSPLIT partial sums per
+// element, then their sum) so that a few thousand slabs still fill the chip; the order is fixed => reproducible.
+#define RSPLIT 32
+__global__ void reduce_partials_stage1(const double* gpart, int64_t slab, int nwg, double* tmp)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= slab) return;
+    const int part = blockIdx.y;
+    const int per = (nwg + RSPLIT - 1) / RSPLIT;
+    const int k0 = part * per, k1 = min(nwg, k0 + per);
+    double s = 0.0;
+    for (int k = k0; k < k1; ++k) s += gpart[int64_t(k) * slab + i];
+    tmp[int64_t(part) * slab + i] = s;
+}
+
+__global__ void reduce_partials_stage2(const double* tmp, int64_t slab, double* out)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= slab) return;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < RSPLIT; ++k) s += tmp[int64_t(k) * slab + i];
+    out[i] = s;
+}
+
 __global__ void reduce_partials_kernel(const double* gpart, int64_t slab, int nwg, double* out)
 {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -329,7 +353,6 @@ __global__ void reduce_partials_kernel(const double* gpart, int64_t slab, int nw
     for (int k = 0; k < nwg; ++k) s += gpart[int64_t(k) * slab + i];
     out[i] = s;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 static const int kNblk[] = {1, 2, 4, 7, 10, 13, 16, 20};
@@ -379,6 +402,7 @@ static PackPtrs pack_ptrs(const cbfssm_pack_layout* L, const double* pack)
     PackPtrs p;
     p.Bp = pack + L->Bp; p.Zp = pack + L->Zp; p.cz = pack + L->cz; p.muA = pack + L->muA; p.s2A = pack + L->s2A;
     p.invl = pack + L->invl; p.scal = pack + L->scal;
+    p.KSr = (L->M + 3) / 4;
     return p;
 }
 
@@ -742,11 +766,20 @@ int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layo
                                            bwd_total_segments(p), rev_chunks(p), nullptr, nullptr, 0, stream);
 }
 
-int cbfssm_reduce_partials_f64(const double* gpart, int64_t slab, int64_t nwg, double* out, void* stream)
+int cbfssm_reduce_partials_f64(double* gpart, int64_t slab, int64_t nwg, double* out, void* stream)
 {
     if (!gpart || !out || slab < 1 || nwg < 1 || nwg > (1 << 30)) return fail(-1, "bad reduce arguments");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(unsigned((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       gpart, slab, int(nwg), out);
+    const unsigned gx = unsigned((slab + 255) / 256);
+    if (nwg >= 4 * RSPLIT) {
+        // the caller's buffer holds nwg slabs; the stage-1 partial sums go to the tail it reserves behind them
+        double* tmp = gpart + nwg * slab;
+        hipLaunchKernelGGL(reduce_partials_stage1, dim3(gx, RSPLIT), dim3(256), 0, (hipStream_t)stream, gpart, slab,
+                           int(nwg), tmp);
+        hipLaunchKernelGGL(reduce_partials_stage2, dim3(gx), dim3(256), 0, (hipStream_t)stream, tmp, slab, out);
+    } else {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, gpart, slab, int(nwg),
+                           out);
+    }
     return check_launch("reduce_partials");
 }
 

@@ -33,6 +33,7 @@ struct PackPtrs {
     const double* s2A;
     const double* invl;
     const double* scal;
+    int KSr;
 };
 
 struct PassArgs {
@@ -83,12 +84,14 @@ struct Tile {
     double Breg[BREG ? RB : 1][BREG ? KS : 1];
     const double* Bp;
     double sigma2;
+    int KSr;       // k-steps of K^-1 that carry data: ceil(M/4) <= KS
 
     template <bool WITH_EPI = true>
     __device__ __forceinline__ void load_operands(const PackPtrs& pk, int w, int l)
     {
         Bp = pk.Bp;
         sigma2 = pk.scal[0];
+        KSr = pk.KSr;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int rb = w * RB + i;
@@ -168,7 +171,7 @@ struct Tile {
             // K^-1 streamed from L2 as a lane-linear A-operand image: 512 contiguous bytes per (row block, k-step)
             static_assert(KS % 4 == 0, "KS must be a multiple of 4");
 #pragma unroll 1
-            for (int s0 = 0; s0 < KS; s0 += 4) {
+            for (int s0 = 0; s0 < KSr; s0 += 4) {
                 double b[4], aop[RB][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

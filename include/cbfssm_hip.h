@@ -216,8 +216,10 @@ int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_l
                                     double* gpart, int seg0, int seg1, int nchunk, double* stash_a, double* stash_k,
                                     int64_t stash_ld, void* stream);
 
-/* out[i] = sum over the nwg slabs, in slab order (bitwise reproducible). */
-int cbfssm_reduce_partials_f64(const double* gpart, int64_t slab, int64_t nwg, double* out, void* stream);
+/* out[i] = sum over the nwg slabs, in a fixed order (bitwise reproducible).  gpart must have room for
+ * nwg + CBFSSM_REDUCE_SPLIT slabs: the tail is scratch for the first of the two reduction stages. */
+#define CBFSSM_REDUCE_SPLIT 32
+int cbfssm_reduce_partials_f64(double* gpart, int64_t slab, int64_t nwg, double* out, void* stream);
 
 #ifdef __cplusplus
 }
