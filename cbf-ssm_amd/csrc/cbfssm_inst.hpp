@@ -10,7 +10,9 @@ namespace cbfssm {
 //                          register file of a CU: 13 blocks x 52 k-steps x 2 VGPRs = 1352 of 2048).
 template <int NBLK>
 struct Cfg {
-    static constexpr int RB = (NBLK > 16) ? 2 : 1;   // (RB = 2 at NBLK = 7 -- 4 waves, 380 VGPRs, one wave per SIMD -- measured 2.6x slower)
+    // (measured at NBLK = 7, C3: 4 waves x 2 row blocks with K^-1 in VGPRs needs 380 registers -> one wave per SIMD,
+    //  2.6x slower; the same with K^-1 streamed from L2 fits two workgroups per CU but is 10-20 % slower than this)
+    static constexpr int RB = (NBLK > 16) ? 2 : 1;
     static constexpr bool BREG = (NBLK <= 7);
 };
 

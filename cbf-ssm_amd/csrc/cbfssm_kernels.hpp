@@ -83,6 +83,9 @@ struct Tile {
     double s2A[RB][4];
     double Breg[BREG ? RB : 1][BREG ? KS : 1];
     const double* Bp;
+    const double* muAg;
+    const double* s2Ag;
+    int lane_;
     double sigma2;
     int KSr;       // k-steps of K^-1 that carry data: ceil(M/4) <= KS
 
@@ -90,6 +93,9 @@ struct Tile {
     __device__ __forceinline__ void load_operands(const PackPtrs& pk, int w, int l)
     {
         Bp = pk.Bp;
+        muAg = pk.muA;
+        s2Ag = pk.s2A;
+        lane_ = l;
         sigma2 = pk.scal[0];
         KSr = pk.KSr;
 #pragma unroll
@@ -102,7 +108,7 @@ struct Tile {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 czr[i][r] = ok ? pk.cz[16 * rbc + 4 * r + (l >> 4)] : -1e30;
-                if (WITH_EPI) {
+                if (WITH_EPI && BREG) {
                     muA[i][r] = ok ? pk.muA[(rbc * 4 + r) * 64 + l] : 0.0;
                     s2A[i][r] = ok ? pk.s2A[(rbc * 4 + r) * 64 + l] : 0.0;
                 }
@@ -203,8 +209,10 @@ struct Tile {
                 const d4 a2 = acc[i][0] + acc[i][1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    P1 = CBF_MFMA(muA[i][r], a2[r], P1);
-                    P2 = CBF_MFMA(s2A[i][r], a2[r] * a2[r], P2);
+                    const double mu_op = BREG ? muA[i][r] : muAg[(rb * 4 + r) * 64 + lane_];
+                    const double s2_op = BREG ? s2A[i][r] : s2Ag[(rb * 4 + r) * 64 + lane_];
+                    P1 = CBF_MFMA(mu_op, a2[r], P1);
+                    P2 = CBF_MFMA(s2_op, a2[r] * a2[r], P2);
                     q = fma(kreg[i][r], a2[r], q);
                 }
             }
