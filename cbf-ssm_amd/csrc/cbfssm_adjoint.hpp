@@ -18,42 +18,6 @@
 
 namespace cbfssm {
 
-// Diagnostic build only (-DCBF_REV_STAMPS): per-phase cycle shares of the adjoint step, compute vs barrier wait, summed
-// over the steps of a pass by lane 0 of every wave into otherwise unused slots of the slab's scalar block
-// (wave 0 -> compute[7] at 100.., wait[7] at 107..; last wave -> 114.., 121..; wave 0 sub-phase marks at 128..).
-// Never defined in the shipped library.
-#ifdef CBF_REV_STAMPS
-#define CBF_STAMP_DECL                                                                                      \
-    unsigned long long st_prev, st_mprev = 0, st_c[7] = {0, 0, 0, 0, 0, 0, 0}, st_w[7] = {0, 0, 0, 0, 0, 0, 0}, \
-                                              st_m[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define CBF_STAMP_READ(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
-#define CBF_STAMP_START() CBF_STAMP_READ(st_prev)
-#define CBF_STAMP_BARRIER(i)                 \
-    {                                        \
-        unsigned long long t1_, t2_;         \
-        CBF_STAMP_READ(t1_);                 \
-        __syncthreads();                     \
-        CBF_STAMP_READ(t2_);                 \
-        st_c[i] += t1_ - st_prev;            \
-        st_w[i] += t2_ - t1_;                \
-        st_prev = t2_;                       \
-    }
-#define CBF_STAMP_MARK(i)                    \
-    {                                        \
-        unsigned long long t1_;              \
-        CBF_STAMP_READ(t1_);                 \
-        st_m[i] += t1_ - st_mprev;           \
-        st_mprev = t1_;                      \
-    }
-#define CBF_STAMP_MARK0() CBF_STAMP_READ(st_mprev)
-#else
-#define CBF_STAMP_DECL
-#define CBF_STAMP_START()
-#define CBF_STAMP_BARRIER(i) __syncthreads()
-#define CBF_STAMP_MARK(i)
-#define CBF_STAMP_MARK0()
-#endif
-
 struct RevPackPtrs {
     const double* muB;   // [NBLK][4][64]   A[row m][k = d]
     const double* s2B;
@@ -257,6 +221,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
 
     CBF_STAMP_DECL;
     CBF_STAMP_START();
+#ifdef CBF_REV_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int step = 0; step < nsteps; ++step) {
         const int t = (MODE == MODE_FWD) ? (a.t_hi - step) : (t_begin + step);
 
@@ -765,6 +732,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             slab[SL::small + o + 7 + i] = double(st_w[i]);
         }
         if (w == 0) for (int i = 0; i < 12; ++i) slab[SL::small + 128 + i] = double(st_m[i]);
+        if (w == 0) {
+            // in-kernel clock: shader cycles per 100 MHz real-time tick (MI355X_MICROARCH.md, DVFS give-back item 6)
+            slab[SL::small + 140] = double(__builtin_amdgcn_s_memtime() - clk0);
+            slab[SL::small + 141] = double(__builtin_amdgcn_s_memrealtime() - rt0);
+        }
     }
 #endif
 }

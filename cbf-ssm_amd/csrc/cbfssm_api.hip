@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdarg>
+#include <cstdlib>
 #include "../../include/cbfssm_hip.h"
 #include "cbfssm_inst.hpp"
 #include "cbfssm_adjoint_inst.hpp"
@@ -15,6 +16,7 @@ CBF_FOR_EACH_REV_NBLK(CBF_REV_DECLARE)
 namespace cbfssm {
 
 static thread_local char g_err[512] = "";
+static double* g_dbg = nullptr;   // diagnostic builds only (cbfssm_debug_set_buffer)
 
 static int fail(int code, const char* fmt, ...)
 {
@@ -367,10 +369,10 @@ static int dispatch_predict(int NBLK, int DK, const PredictArgs& a, hipStream_t 
     return -2;
 }
 
-static int dispatch_pass(int NBLK, int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st)
+static int dispatch_pass(int NBLK, int DK, int mode, const PassArgs& a, dim3 grid, int nc, hipStream_t st)
 {
     switch (NBLK) {
-#define X(NB) case NB: return launch_pass_nb##NB(DK, mode, a, grid, st);
+#define X(NB) case NB: return launch_pass_nb##NB(DK, mode, a, grid, nc, st);
         CBF_FOR_EACH_NBLK(X)
 #undef X
     }
@@ -420,6 +422,20 @@ static int check_problem(const cbfssm_problem* p, const cbfssm_pack_layout* L, i
     return 0;
 }
 
+// column blocks (16 chains each) per workgroup of the forward-evaluation pass kernels: two when there are enough
+// chains to still cover the chip (every K^-1 operand then feeds two MFMAs and every barrier covers twice the work)
+static int pass_nc(const cbfssm_problem* p, int mode)
+{
+    if (p->M > 112) return 1;     // two column blocks of the larger tiles do not fit the LDS
+    const int64_t n = int64_t(p->B) * p->S;
+    const char* e = getenv(mode == MODE_FWD ? "CBFSSM_NC_FWD" : "CBFSSM_NC_BWD");
+    if (e) return atoi(e) == 2 ? 2 : 1;
+    // measured at C3: the skewed two-group kernel is 3 % faster on the many-workgroup backward runs and 2 % slower
+    // on the forward pass (320 -> 160 workgroups)
+    if (mode == MODE_BWD) return n >= 32 * 128 ? 2 : 1;
+    return 1;
+}
+
 static void bwd_segments(const cbfssm_problem* p, int* nseg0, int* nseg1)
 {
     const int P = 2 * p->recog_len;
@@ -434,6 +450,9 @@ using namespace cbfssm;
 extern "C" {
 
 const char* cbfssm_last_error(void) { return g_err; }
+#ifdef CBF_REV_STAMPS
+void cbfssm_debug_set_buffer(double* p) { g_dbg = p; }
+#endif
 int cbfssm_version(void) { return 1; }
 
 int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out)
@@ -546,7 +565,8 @@ int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p)
     if (!p || p->recog_len < 1) return -1;
     int n0, n1;
     bwd_segments(p, &n0, &n1);
-    const int64_t groups = (int64_t(p->B) * p->S + 15) / 16;
+    const int nc = pass_nc(p, MODE_BWD);
+    const int64_t groups = (int64_t(p->B) * p->S + 16 * nc - 1) / (16 * nc);
     return groups * (n0 + n1);
 }
 
@@ -566,11 +586,13 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = p->k_factor;
     a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.y2_out = y2; a.h_all = h_all;
     a.part_out = ent_part;
+    a.dbg = g_dbg;
     int n0, n1;
     bwd_segments(p, &n0, &n1);
     a.nseg0 = n0;
-    dim3 grid(unsigned((a.N + 15) / 16), unsigned(n0 + n1));
-    rc = dispatch_pass(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
+    const int nc = pass_nc(p, MODE_BWD);
+    dim3 grid(unsigned((a.N + 16 * nc - 1) / (16 * nc)), unsigned(n0 + n1));
+    rc = dispatch_pass(L->NBLK, L->DK, MODE_BWD, a, grid, nc, (hipStream_t)stream);
     if (rc) return fail(rc, "backward_pass launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
 }
@@ -578,7 +600,8 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
 int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p)
 {
     if (!p) return -1;
-    return (int64_t(p->B) * p->S + 15) / 16;
+    const int nc = pass_nc(p, MODE_FWD);
+    return (int64_t(p->B) * p->S + 16 * nc - 1) / (16 * nc);
 }
 
 int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
@@ -598,8 +621,10 @@ int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L
     a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = p->k_factor;
     a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x;
     a.part_out = kl_part;
-    dim3 grid(unsigned((a.N + 15) / 16), 1);
-    rc = dispatch_pass(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
+    a.dbg = g_dbg;
+    const int nc = pass_nc(p, MODE_FWD);
+    dim3 grid(unsigned((a.N + 16 * nc - 1) / (16 * nc)), 1);
+    rc = dispatch_pass(L->NBLK, L->DK, MODE_FWD, a, grid, nc, (hipStream_t)stream);
     if (rc) return fail(rc, "forward_pass launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
 }

@@ -43,16 +43,24 @@ int launch_predict_t(const PredictArgs& a, hipStream_t st)
 }
 
 template <int NBLK, int DK, int MODE>
-int launch_pass_t(const PassArgs& a, dim3 grid, hipStream_t st)
+int launch_pass_t(const PassArgs& a, dim3 grid, int nc, hipStream_t st)
 {
     typedef Cfg<NBLK> C;
     typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
-    const size_t lds = TT::LDS_DOUBLES * sizeof(double);
-    auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE>;
-    int rc = set_lds(k, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
-    hipError_t e = hipGetLastError();
+    const size_t lds = (size_t(nc) * (TT::LDS_DOUBLES - 64) + 64) * sizeof(double);
+    hipError_t e;
+    if (nc == 2) {
+        auto k = pass_kernel_skew<NBLK, C::RB, DK, C::BREG, MODE>;
+        int rc = set_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
+    } else {
+        auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 1>;
+        int rc = set_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
+    }
+    e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
 }
 
@@ -68,19 +76,19 @@ int launch_predict_n(int DK, const PredictArgs& a, hipStream_t st)
 }
 
 template <int NBLK>
-int launch_pass_n(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st)
+int launch_pass_n(int DK, int mode, const PassArgs& a, dim3 grid, int nc, hipStream_t st)
 {
     if (mode == MODE_FWD) {
         switch (DK) {
-            case 2: return launch_pass_t<NBLK, 2, MODE_FWD>(a, grid, st);
-            case 4: return launch_pass_t<NBLK, 4, MODE_FWD>(a, grid, st);
-            case 6: return launch_pass_t<NBLK, 6, MODE_FWD>(a, grid, st);
+            case 2: return launch_pass_t<NBLK, 2, MODE_FWD>(a, grid, nc, st);
+            case 4: return launch_pass_t<NBLK, 4, MODE_FWD>(a, grid, nc, st);
+            case 6: return launch_pass_t<NBLK, 6, MODE_FWD>(a, grid, nc, st);
         }
     } else {
         switch (DK) {
-            case 2: return launch_pass_t<NBLK, 2, MODE_BWD>(a, grid, st);
-            case 4: return launch_pass_t<NBLK, 4, MODE_BWD>(a, grid, st);
-            case 6: return launch_pass_t<NBLK, 6, MODE_BWD>(a, grid, st);
+            case 2: return launch_pass_t<NBLK, 2, MODE_BWD>(a, grid, nc, st);
+            case 4: return launch_pass_t<NBLK, 4, MODE_BWD>(a, grid, nc, st);
+            case 6: return launch_pass_t<NBLK, 6, MODE_BWD>(a, grid, nc, st);
         }
     }
     return -2;
@@ -91,7 +99,7 @@ int launch_pass_n(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st
 #define CBF_DECLARE(NB)                                                                          \
     namespace cbfssm {                                                                           \
     int launch_predict_nb##NB(int DK, const PredictArgs& a, hipStream_t st);                     \
-    int launch_pass_nb##NB(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st);      \
+    int launch_pass_nb##NB(int DK, int mode, const PassArgs& a, dim3 grid, int nc, hipStream_t st); \
     }
 
 #define CBF_INSTANTIATE(NB)                                                                      \
@@ -100,9 +108,9 @@ int launch_pass_n(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st
     {                                                                                            \
         return launch_predict_n<NB>(DK, a, st);                                                  \
     }                                                                                            \
-    int launch_pass_nb##NB(int DK, int mode, const PassArgs& a, dim3 grid, hipStream_t st)       \
+    int launch_pass_nb##NB(int DK, int mode, const PassArgs& a, dim3 grid, int nc, hipStream_t st) \
     {                                                                                            \
-        return launch_pass_n<NB>(DK, mode, a, grid, st);                                         \
+        return launch_pass_n<NB>(DK, mode, a, grid, nc, st);                                     \
     }                                                                                            \
     }
 

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace cbfssm {
 
@@ -24,6 +25,46 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define CBF_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 enum { MODE_FWD = 0, MODE_BWD = 1 };
+
+// Diagnostic build only (-DCBF_REV_STAMPS): per-phase cycle shares of the adjoint step, compute vs barrier wait, summed
+// over the steps of a pass by lane 0 of every wave into otherwise unused slots of the slab's scalar block
+// (wave 0 -> compute[7] at 100.., wait[7] at 107..; last wave -> 114.., 121..; wave 0 sub-phase marks at 128..).
+// Never defined in the shipped library.
+#ifdef CBF_REV_STAMPS
+#define CBF_STAMP_DECL                                                                                      \
+    unsigned long long st_prev, st_mprev = 0, st_c[7] = {0, 0, 0, 0, 0, 0, 0}, st_w[7] = {0, 0, 0, 0, 0, 0, 0}, \
+                                              st_m[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define CBF_STAMP_READ(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#define CBF_STAMP_START() CBF_STAMP_READ(st_prev)
+#define CBF_STAMP_BARRIER(i)                 \
+    {                                        \
+        unsigned long long t1_, t2_;         \
+        CBF_STAMP_READ(t1_);                 \
+        __syncthreads();                     \
+        CBF_STAMP_READ(t2_);                 \
+        st_c[i] += t1_ - st_prev;            \
+        st_w[i] += t2_ - t1_;                \
+        st_prev = t2_;                       \
+    }
+#define CBF_STAMP_MARK(i)                    \
+    {                                        \
+        unsigned long long t1_;              \
+        CBF_STAMP_READ(t1_);                 \
+        st_m[i] += t1_ - st_mprev;           \
+        st_mprev = t1_;                      \
+    }
+#define CBF_STAMP_MARK0() CBF_STAMP_READ(st_mprev)
+#define CBF_STAMP_GP_BARRIER() __syncthreads()
+#else
+#define CBF_STAMP_DECL
+#define CBF_STAMP_START()
+#define CBF_STAMP_BARRIER(i) __syncthreads()
+#define CBF_STAMP_MARK(i)
+#define CBF_STAMP_MARK0()
+#define CBF_STAMP_GP_BARRIER() __syncthreads()
+#endif
+
+
 
 struct PackPtrs {
     const double* Bp;
@@ -56,6 +97,7 @@ struct PassArgs {
     double* x_out;         // fwd: (T,N,dim_x)
     double* part_out;      // one partial per workgroup
     int nseg0;             // bwd: number of segment slots of run 0 (blockIdx.y < nseg0 -> run 0)
+    double* dbg;           // diagnostic builds: [workgroup][32] stamp sums (null otherwise)
 };
 
 struct PredictArgs {
@@ -74,7 +116,7 @@ struct Tile {
     static constexpr int MP = 16 * NBLK;
     static constexpr int KS = MP / 4;                // k-steps of the K^-1 K product
     static constexpr int QPW = (4 + W - 1) / W;      // state-row groups (4 rows each) per wave in phase 3
-    static constexpr int LDS_DOUBLES = DK * 64 + MP * 16 + W * 512 + 64;
+    static constexpr int LDS_DOUBLES = DK * 64 + MP * 16 + W * 512 + 64;   // per column block (+64 once)
 
     // loop-invariant MFMA A operands of this wave
     double Zreg[RB][DK];
@@ -120,11 +162,132 @@ struct Tile {
         }
     }
 
-    // phases 1 and 2 for the 16 points whose scaled inputs sit in xq; leaves P1/P2 partials of this wave in `part`.
-    // Contains two workgroup barriers; the caller must barrier before reading `part` and before rewriting xq.
+    // phases 1 and 2 for NC column blocks of 16 points whose scaled inputs sit in xq[c]; leaves the P1/P2 partials
+    // of this wave in part[c].  Contains one workgroup barrier; the caller must barrier before reading `part` and
+    // before rewriting xq.  With NC = 2 every K^-1 operand feeds two MFMAs (two independent accumulator chains).
+    template <int NC>
     __device__ __forceinline__ void gp_phases(const double* xq, double* Kt, double* part, int w, int l)
     {
+        constexpr int XS = DK * 64, KTS = MP * 16, PS = W * 512;
         // ---- phase 1: kernel tile rows of this wave
+        double kreg[NC][RB][4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double bx[DK];
+            double xx = 0.0;
+#pragma unroll
+            for (int s = 0; s < DK; ++s) {
+                bx[s] = xq[c * XS + 64 * s + l];
+                xx = fma(bx[s], bx[s], xx);
+            }
+            xx += __shfl_xor(xx, 16);
+            xx += __shfl_xor(xx, 32);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int rb = w * RB + i;
+                if (rb < NBLK) {
+                    d4 e;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[r] = czr[i][r] - 0.5 * xx;
+#pragma unroll
+                    for (int s = 0; s < DK; ++s) e = CBF_MFMA(Zreg[i][s], bx[s], e);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        kreg[c][i][r] = exp(e[r]);
+                        Kt[c * KTS + 256 * rb + 64 * r + l] = kreg[c][i][r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kreg[c][i][r] = 0.0;
+                }
+            }
+        }
+        CBF_STAMP_GP_BARRIER();
+
+        // ---- phase 2: A2 rows of this wave, then the P1/P2 products
+        constexpr int two = (RB * NC == 1) ? 1 : 0;
+        d4 acc[NC][RB][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) { acc[c][i][0] = d4{0, 0, 0, 0}; acc[c][i][1] = d4{0, 0, 0, 0}; }
+        if constexpr (BREG) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double b[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) b[c] = Kt[c * KTS + 64 * s + l];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int rb = w * RB + i;
+                    if (rb < NBLK) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            acc[c][i][(s & 1) * two] = CBF_MFMA(Breg[i][s], b[c], acc[c][i][(s & 1) * two]);
+                    }
+                }
+            }
+        } else {
+            // K^-1 streamed from L2 as a lane-linear A-operand image: 512 contiguous bytes per (row block, k-step)
+            static_assert(KS % 4 == 0, "KS must be a multiple of 4");
+#pragma unroll 1
+            for (int s0 = 0; s0 < KSr; s0 += 4) {
+                double b[NC][4], aop[RB][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) b[c][j] = Kt[c * KTS + 64 * (s0 + j) + l];
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) {
+                        const int rb = min(w * RB + i, NBLK - 1);
+                        aop[i][j] = Bp[(rb * KS + s0 + j) * 64 + l];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) {
+                        if (w * RB + i < NBLK) {
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                acc[c][i][(j & 1) * two] = CBF_MFMA(aop[i][j], b[c][j], acc[c][i][(j & 1) * two]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int rb = w * RB + i;
+                if (rb < NBLK) {
+                    const d4 a2 = acc[c][i][0] + acc[c][i][1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double mu_op = BREG ? muA[i][r] : muAg[(rb * 4 + r) * 64 + lane_];
+                        const double s2_op = BREG ? s2A[i][r] : s2Ag[(rb * 4 + r) * 64 + lane_];
+                        P1 = CBF_MFMA(mu_op, a2[r], P1);
+                        P2 = CBF_MFMA(s2_op, a2[r] * a2[r], P2);
+                        q = fma(kreg[c][i][r], a2[r], q);
+                    }
+                }
+            }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                part[c * PS + ((w * 2 + 0) * 4 + r) * 64 + l] = P1[r];
+                part[c * PS + ((w * 2 + 1) * 4 + r) * 64 + l] = P2[r] - q;
+            }
+        }
+    }
+
+    // ---- the same two phases as separate calls on ONE column block (used by the skewed two-group pipeline)
+    __device__ __forceinline__ void phase1(const double* xq, double* Kt, double (&kreg)[RB][4], int w, int l)
+    {
         double bx[DK];
         double xx = 0.0;
 #pragma unroll
@@ -134,7 +297,6 @@ struct Tile {
         }
         xx += __shfl_xor(xx, 16);
         xx += __shfl_xor(xx, 32);
-        double kreg[RB][4];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int rb = w * RB + i;
@@ -154,9 +316,10 @@ struct Tile {
                 for (int r = 0; r < 4; ++r) kreg[i][r] = 0.0;
             }
         }
-        __syncthreads();
+    }
 
-        // ---- phase 2: A2 rows of this wave, then the P1/P2 products
+    __device__ __forceinline__ void phase2(const double* Kt, double* part, const double (&kreg)[RB][4], int w, int l)
+    {
         d4 acc[RB][2];
 #pragma unroll
         for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
@@ -165,17 +328,10 @@ struct Tile {
             for (int s = 0; s < KS; ++s) {
                 const double b = Kt[64 * s + l];
 #pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int rb = w * RB + i;
-                    if (rb < NBLK) {
-                        constexpr int two = (RB == 1) ? 1 : 0;
-                        acc[i][(s & 1) * two] = CBF_MFMA(Breg[i][s], b, acc[i][(s & 1) * two]);
-                    }
-                }
+                for (int i = 0; i < RB; ++i)
+                    if (w * RB + i < NBLK) acc[i][s & 1] = CBF_MFMA(Breg[i][s], b, acc[i][s & 1]);
             }
         } else {
-            // K^-1 streamed from L2 as a lane-linear A-operand image: 512 contiguous bytes per (row block, k-step)
-            static_assert(KS % 4 == 0, "KS must be a multiple of 4");
 #pragma unroll 1
             for (int s0 = 0; s0 < KSr; s0 += 4) {
                 double b[4], aop[RB][4];
@@ -183,21 +339,13 @@ struct Tile {
                 for (int j = 0; j < 4; ++j) {
                     b[j] = Kt[64 * (s0 + j) + l];
 #pragma unroll
-                    for (int i = 0; i < RB; ++i) {
-                        const int rb = min(w * RB + i, NBLK - 1);
-                        aop[i][j] = Bp[(rb * KS + s0 + j) * 64 + l];
-                    }
+                    for (int i = 0; i < RB; ++i) aop[i][j] = Bp[(min(w * RB + i, NBLK - 1) * KS + s0 + j) * 64 + l];
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < RB; ++i) {
-                        if (w * RB + i < NBLK) {
-                            constexpr int two = (RB == 1) ? 1 : 0;
-                            acc[i][(j & 1) * two] = CBF_MFMA(aop[i][j], b[j], acc[i][(j & 1) * two]);
-                        }
-                    }
-                }
+                    for (int i = 0; i < RB; ++i)
+                        if (w * RB + i < NBLK) acc[i][j & 1] = CBF_MFMA(aop[i][j], b[j], acc[i][j & 1]);
             }
         }
         d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
@@ -293,7 +441,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(Pr
         xq[i] = v;
     }
     __syncthreads();
-    tile.gp_phases(xq, Kt, part, w, l);
+    tile.template gp_phases<1>(xq, Kt, part, w, l);
     __syncthreads();
 #pragma unroll
     for (int qi = 0; qi < TT::QPW; ++qi) {
@@ -314,26 +462,27 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(Pr
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent pass kernel.  MODE_FWD: CBFSSM._forward_body loop (cbfssm.py:176-237);
 // MODE_BWD: one resample-to-resample segment of one CBFSSM._backward_body run (cbfssm.py:107-158).
+// NC: column blocks (16 chains each) per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBLK, int RB, int DK, bool BREG, int MODE>
+template <int NBLK, int RB, int DK, bool BREG, int MODE, int NC>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassArgs a)
 {
     typedef Tile<NBLK, RB, DK, BREG> TT;
-    constexpr int W = TT::W, NT = TT::NT, QPW = TT::QPW;
+    constexpr int W = TT::W, NT = TT::NT;
+    constexpr int NTASK = 4 * NC;                    // (state-row group q, column block) pairs of phase 3
+    constexpr int QPW = (NTASK + W - 1) / W;
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
+    constexpr int XS = DK * 64, KTS = TT::MP * 16, PS = W * 512;
     extern __shared__ double lds[];
-    double* xq = lds;
-    double* Kt = xq + DK * 64;
-    double* part = Kt + TT::MP * 16;
-    double* red = part + W * 512;
+    double* xq = lds;                                // [NC][DK*64]
+    double* Kt = xq + NC * XS;                       // [NC][MP*16]
+    double* part = Kt + NC * KTS;                    // [NC][W][512]
+    double* red = part + NC * PS;
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do;
     const int naux = a.D - Do;                       // rows of the GP input that are not chain state
-    const int c0 = blockIdx.x * 16;
-    const int c = min(c0 + nl, N - 1);               // clamped chain of this lane (phase 3)
-    const bool cvalid = (c0 + nl) < N;
-    const int bq = c / S;                            // its sequence
+    const int c0 = blockIdx.x * 16 * NC;
 
     // ---- time range of this workgroup
     int t_first, nsteps, dir, run = 0;
@@ -357,17 +506,24 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     TT tile;
     tile.load_operands(a.pk, w, l);
 
-    // per-lane constants of the state rows this lane finishes in phase 3
+    // per-lane constants of the phase-3 tasks of this wave: task tk = w + qi*W -> (q = tk & 3, column block tk >> 2)
     double vx[QPW], vy[QPW], il[QPW];
     double hcur[QPW];
     double lin[QPW];
     LogProd lp[QPW];
-    bool act[QPW];
+    bool act[QPW], cval[QPW];
+    int cc[QPW], bqv[QPW], qv[QPW], cbv[QPW];
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
-        const int q = w + qi * W;
-        const int d = 4 * q + g;
-        act[qi] = (q < 4) && (d < Do);
+        const int tk = w + qi * W;
+        qv[qi] = tk & 3;
+        cbv[qi] = (tk >> 2) < NC ? (tk >> 2) : (NC - 1);
+        const int d = 4 * qv[qi] + g;
+        const int cg = c0 + cbv[qi] * 16 + nl;
+        cc[qi] = min(cg, N - 1);
+        cval[qi] = cg < N;
+        bqv[qi] = cc[qi] / S;
+        act[qi] = (tk < NTASK) && (d < Do);
         const int dc = act[qi] ? d : 0;
         vx[qi] = a.var_x[dc];
         vy[qi] = (MODE == MODE_FWD) ? a.var_y[dc] : 0.0;
@@ -378,11 +534,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     }
 
     // auxiliary (non-state) input rows: fwd u_t; bwd [u_t, y_t]           (cbfssm.py:137,197)
-    auto aux_load = [&](int i, int t) -> double {
+    auto aux_load = [&](int cb, int i, int t) -> double {
         const int ja = i >> 4, n = i & 15;
         if (ja >= naux) return 0.0;
-        const int cc = min(c0 + n, N - 1);
-        const int b = cc / S;
+        const int cx = min(c0 + cb * 16 + n, N - 1);
+        const int b = cx / S;
         double v;
         if (ja < a.dim_u) v = a.u[(int64_t(b) * T + t) * a.dim_u + ja];
         else v = a.y[(int64_t(b) * T + t) * a.dim_y + (ja - a.dim_u)];
@@ -391,75 +547,90 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 
     // ---- initial state and first input
     // xq rows [0,Do) carry the chain state, rows [Do,D) the auxiliary inputs, rows [D,4*DK) stay zero
-    for (int i = tid; i < DK * 64; i += NT) xq[i] = 0.0;
+    for (int i = tid; i < NC * XS; i += NT) xq[i] = 0.0;
     __syncthreads();
     const bool resample0 = (MODE == MODE_BWD) && (((t_first + 1 + run * R) % P) == 0);
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
-        const int q = w + qi * W;
-        const int d = 4 * q + g;
+        const int d = 4 * qv[qi] + g;
+        const int c = cc[qi];
         if (act[qi]) {
             double v;
             if (MODE == MODE_FWD) {
                 // x_0 = y_tilde[:, 0] = [y_0, y2_0]                       (cbfssm.py:97,168)
-                v = (d < a.dim_y) ? a.y[(int64_t(bq) * T) * a.dim_y + d]
+                v = (d < a.dim_y) ? a.y[(int64_t(bqv[qi]) * T) * a.dim_y + d]
                                   : a.y2_in[int64_t(c) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
-                if (cvalid) a.x_out[int64_t(c) * a.dim_x + d] = v;
+                if (cval[qi]) a.x_out[int64_t(c) * a.dim_x + d] = v;
             } else {
                 v = resample0 ? a.hid[(int64_t(run) * T + t_first) * N + c] : 0.0;   // cbfssm.py:106,133-136
             }
             hcur[qi] = v;
-            xq[64 * q + l] = v * il[qi];
+            xq[cbv[qi] * XS + 64 * qv[qi] + l] = v * il[qi];
         }
     }
-    double auxr[AUXR];
+    double auxr[NC][AUXR];
 #pragma unroll
-    for (int k2 = 0; k2 < AUXR; ++k2) {
-        const int i = tid + k2 * NT;
-        if (i < 16 * naux) xq[16 * Do + i] = aux_load(i, t_first);
-    }
+    for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+        for (int k2 = 0; k2 < AUXR; ++k2) {
+            const int i = tid + k2 * NT;
+            if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = aux_load(cb, i, t_first);
+        }
 
+    CBF_STAMP_DECL;
+    CBF_STAMP_START();
     for (int step = 0; step < nsteps; ++step) {
         const int t = t_first + dir * step;
         const int tn = t + dir;                       // time index of the next GP input
         const bool has_next = (step + 1 < nsteps);
-        __syncthreads();                              // xq complete
+        CBF_STAMP_BARRIER(0);                         // xq complete
 
         // ---- prefetch this step's epilogue inputs and the next step's auxiliary rows
-        double eps_t, ytil[QPW], hidn = 0.0;
+        double eps_t[QPW], ytil[QPW], hidn[QPW];
         bool resample_n = false;
-        if (MODE == MODE_FWD) {
-            eps_t = a.eps[int64_t(t) * N + c];                                         // cbfssm.py:209
+        if (MODE == MODE_BWD) resample_n = has_next && (((tn + 1 + run * R) % P) == 0);     // cbfssm.py:124,127
 #pragma unroll
-            for (int qi = 0; qi < QPW; ++qi) {
-                const int d = 4 * (w + qi * W) + g;
-                ytil[qi] = 0.0;
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int c = cc[qi];
+            const int d = 4 * qv[qi] + g;
+            ytil[qi] = 0.0; hidn[qi] = 0.0;
+            if (MODE == MODE_FWD) {
+                eps_t[qi] = a.eps[int64_t(t) * N + c];                                       // cbfssm.py:209
                 if (act[qi]) {
-                    ytil[qi] = (d < a.dim_y) ? a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d]      // cbfssm.py:196
+                    ytil[qi] = (d < a.dim_y) ? a.y[(int64_t(bqv[qi]) * T + (t + 1)) * a.dim_y + d]    // cbfssm.py:196
                                              : a.y2_in[(int64_t(t + 1) * N + c) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
                 }
+            } else {
+                eps_t[qi] = a.eps[(int64_t(run) * T + t) * N + c];                           // cbfssm.py:149
+                if (resample_n) hidn[qi] = a.hid[(int64_t(run) * T + tn) * N + c];
             }
-        } else {
-            eps_t = a.eps[(int64_t(run) * T + t) * N + c];                             // cbfssm.py:149
-            resample_n = has_next && (((tn + 1 + run * R) % P) == 0);                  // cbfssm.py:124,127
-            if (resample_n) hidn = a.hid[(int64_t(run) * T + tn) * N + c];
         }
 #pragma unroll
-        for (int k2 = 0; k2 < AUXR; ++k2) {
-            const int i = tid + k2 * NT;
-            auxr[k2] = (has_next && i < 16 * naux) ? aux_load(i, tn) : 0.0;
-        }
+        for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+            for (int k2 = 0; k2 < AUXR; ++k2) {
+                const int i = tid + k2 * NT;
+                auxr[cb][k2] = (has_next && i < 16 * naux) ? aux_load(cb, i, tn) : 0.0;
+            }
 
-        tile.gp_phases(xq, Kt, part, w, l);
-        __syncthreads();                              // part complete; xq and Kt free
+        if constexpr (NC == 1) {
+            double kr[RB][4];
+            tile.phase1(xq, Kt, kr, w, l);
+            CBF_STAMP_BARRIER(1);
+            tile.phase2(Kt, part, kr, w, l);
+        } else {
+            tile.template gp_phases<NC>(xq, Kt, part, w, l);
+        }
+        CBF_STAMP_BARRIER(2);                         // part complete; xq and Kt free
 
         // ---- phase 3
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
-            const int q = w + qi * W;
-            if (q < 4) {
+            const int tk = w + qi * W;
+            if (tk < NTASK) {
+                const int q = qv[qi], cb = cbv[qi], c = cc[qi];
                 double fm, fv;
-                tile.gather(part, q, l, fm, fv);
+                tile.gather(part + cb * PS, q, l, fm, fv);
                 const int d = 4 * q + g;
                 double outv = 0.0;
                 if (act[qi]) {
@@ -468,25 +639,25 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                     if (MODE == MODE_FWD) {
                         const double vyt = vy[qi] + (a.k_factor - 1.0) * fvar;         // cbfssm.py:212-214
                         const double s = vyt + fvar;                                   // :216
-                        const double k = fvar * (1.0 / s);                             // :217
+                        const double kk = fvar * (1.0 / s);                            // :217
                         const double ydiff = ytil[qi] - fmean;                         // :215
-                        const double mu = fmean + k * ydiff;                           // :218
-                        const double omk = 1.0 - k;
-                        const double sig = omk * omk * fvar + k * k * vyt;             // :219-220
+                        const double mu = fmean + kk * ydiff;                          // :218
+                        const double omk = 1.0 - kk;
+                        const double sig = omk * omk * fvar + kk * kk * vyt;           // :219-220
                         const bool do_cond = a.condition || (t < R - 1);               // :227
-                        outv = do_cond ? (mu + eps_t * sqrt(sig)) : (fmean + eps_t * sqrt(fvar));   // :221-229
-                        if (do_cond && cvalid) {
+                        outv = do_cond ? (mu + eps_t[qi] * sqrt(sig)) : (fmean + eps_t[qi] * sqrt(fvar));   // :221-229
+                        if (do_cond && cval[qi]) {
                             // kl_reg = log fvar - log sig + (sig + (mu - fmean)^2)/fvar - 1        (:232)
                             const double rf = 1.0 / fvar;
                             const double dm = mu - fmean;
                             lin[qi] += (sig + dm * dm) * rf - 1.0;
                             lp[qi].mul(sig * rf);
                         }
-                        if (cvalid) a.x_out[(int64_t(t + 1) * N + c) * a.dim_x + d] = outv;         // :229
+                        if (cval[qi]) a.x_out[(int64_t(t + 1) * N + c) * a.dim_x + d] = outv;       // :229
                     } else {
-                        outv = fmean + eps_t * sqrt(fvar);                             // cbfssm.py:150
+                        outv = fmean + eps_t[qi] * sqrt(fvar);                         // cbfssm.py:150
                         const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);             // :125,128
-                        if (cvalid) {
+                        if (cval[qi]) {
                             if (write) {
                                 a.y2_out[(int64_t(t) * N + c) * Do + d] = outv;        // :151
                                 lp[qi].mul(fvar);                                      // :154-156
@@ -496,17 +667,19 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                         }
                     }
                 }
-                const double hn = (MODE == MODE_BWD && resample_n) ? hidn : outv;      // cbfssm.py:133-136,158
+                const double hn = (MODE == MODE_BWD && resample_n) ? hidn[qi] : outv;  // cbfssm.py:133-136,158
                 hcur[qi] = act[qi] ? hn : 0.0;
-                if (has_next && act[qi]) xq[64 * q + l] = hn * il[qi];
+                if (has_next && act[qi]) xq[cb * XS + 64 * q + l] = hn * il[qi];
             }
         }
         if (has_next) {
 #pragma unroll
-            for (int k2 = 0; k2 < AUXR; ++k2) {
-                const int i = tid + k2 * NT;
-                if (i < 16 * naux) xq[16 * Do + i] = auxr[k2];
-            }
+            for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+                for (int k2 = 0; k2 < AUXR; ++k2) {
+                    const int i = tid + k2 * NT;
+                    if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = auxr[cb][k2];
+                }
         }
     }
 
@@ -514,11 +687,272 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     double v = 0.0;
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
-        if (act[qi] && cvalid) {
+        if (act[qi] && cval[qi]) {
             if (MODE == MODE_FWD) v += 0.5 * (lin[qi] - lp[qi].log());
             else v += 0.5 * (lin[qi] * 2.8378770664093453391 + lp[qi].log());          // log(2 pi e)
         }
     }
+    const double tot = block_sum(v, red, tid, NT);
+    if (tid == 0) a.part_out[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+#ifdef CBF_REV_STAMPS
+    if (a.dbg && l == 0 && (w == 0 || w == W - 1)) {
+        double* o = a.dbg + (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * 64 + (w == 0 ? 0 : 32);
+        for (int i = 0; i < 7; ++i) { o[i] = double(st_c[i]); o[7 + i] = double(st_w[i]); }
+        for (int i = 0; i < 12; ++i) o[14 + i] = double(st_m[i]);
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skewed two-group pass kernel: one workgroup carries TWO column blocks (A, B: 16 chains each) half a step apart, so
+// that every barrier interval pairs matrix work of one group with the VALU-heavy epilogue / kernel-tile work of the
+// other (3 barriers per step of both groups instead of 6):
+//     alpha:  phase2(A, s)              ||  phase3(B, s-1)
+//     beta :  phase3(A, s)              ||  phase1(B, s)
+//     gamma:  phase1(A, s+1)            ||  phase2(B, s)
+// Phase-3 work of A sits on the low waves, of B on the high waves (SIMD partners w, w+4 get different mixes).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NBLK, int RB, int DK, bool BREG, int MODE>
+__global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(PassArgs a)
+{
+    typedef Tile<NBLK, RB, DK, BREG> TT;
+    constexpr int W = TT::W, NT = TT::NT;
+    constexpr int QPW = TT::QPW;                     // phase-3 tasks per wave and group
+    constexpr int AUXR = (DK * 64 + NT - 1) / NT;
+    constexpr int XS = DK * 64, KTS = TT::MP * 16, PS = W * 512;
+    extern __shared__ double lds[];
+    double* xq = lds;                                // [2][DK*64]
+    double* Kt = xq + 2 * XS;                        // [2][MP*16]
+    double* part = Kt + 2 * KTS;                     // [2][W][512]
+    double* red = part + 2 * PS;
+
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
+    const int N = a.N, S = a.S, T = a.T, Do = a.Do;
+    const int naux = a.D - Do;
+    const int c0 = blockIdx.x * 32;
+
+    int t_first, nsteps, dir, run = 0;
+    const int R = a.recog_len, P = 2 * R;
+    if (MODE == MODE_FWD) {
+        t_first = 0; nsteps = T - 1; dir = 1;
+    } else {
+        int k;
+        if (int(blockIdx.y) < a.nseg0) { run = 0; k = blockIdx.y + 1; }
+        else { run = 1; k = blockIdx.y - a.nseg0 + 1; }
+        const int o = run * R;
+        const int hi = min(P * k - 1 - o, T - 1);
+        const int lo = (k > 1) ? (P * (k - 1) - o) : 0;
+        t_first = hi; nsteps = hi - lo + 1; dir = -1;
+        if (nsteps <= 0) {
+            if (tid == 0) a.part_out[blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
+            return;
+        }
+    }
+
+    TT tile;
+    tile.load_operands(a.pk, w, l);
+
+    // phase-3 tasks: group c, row group q = wq + qi*W (< 4) with wq = w for group A and W-1-w for group B
+    double vx[2][QPW], vy[2][QPW], il[2][QPW], hcur[2][QPW], lin[2][QPW];
+    LogProd lp[2][QPW];
+    bool act[2][QPW], cval[2];
+    int cc[2], bqv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int cg = c0 + c * 16 + nl;
+        cc[c] = min(cg, N - 1);
+        cval[c] = cg < N;
+        bqv[c] = cc[c] / S;
+        const int wq = (c == 0) ? w : (W - 1 - w);
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int q = wq + qi * W;
+            const int d = 4 * q + g;
+            act[c][qi] = (q < 4) && (d < Do);
+            const int dc = act[c][qi] ? d : 0;
+            vx[c][qi] = a.var_x[dc];
+            vy[c][qi] = (MODE == MODE_FWD) ? a.var_y[dc] : 0.0;
+            il[c][qi] = a.pk.invl[dc];
+            lin[c][qi] = 0.0;
+            lp[c][qi].init();
+            hcur[c][qi] = 0.0;
+        }
+    }
+
+    auto aux_load = [&](int cb, int i, int t) -> double {
+        const int ja = i >> 4, n = i & 15;
+        if (ja >= naux) return 0.0;
+        const int cx = min(c0 + cb * 16 + n, N - 1);
+        const int b = cx / S;
+        double v;
+        if (ja < a.dim_u) v = a.u[(int64_t(b) * T + t) * a.dim_u + ja];
+        else v = a.y[(int64_t(b) * T + t) * a.dim_y + (ja - a.dim_u)];
+        return v * a.pk.invl[Do + ja];
+    };
+
+    // ---- initial state and first input of both groups
+    for (int i = tid; i < 2 * XS; i += NT) xq[i] = 0.0;
+    __syncthreads();
+    const bool resample0 = (MODE == MODE_BWD) && (((t_first + 1 + run * R) % P) == 0);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int wq = (c == 0) ? w : (W - 1 - w);
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int q = wq + qi * W;
+            const int d = 4 * q + g;
+            if (act[c][qi]) {
+                double v;
+                if (MODE == MODE_FWD) {
+                    v = (d < a.dim_y) ? a.y[(int64_t(bqv[c]) * T) * a.dim_y + d]
+                                      : a.y2_in[int64_t(cc[c]) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
+                    if (cval[c]) a.x_out[int64_t(cc[c]) * a.dim_x + d] = v;
+                } else {
+                    v = resample0 ? a.hid[(int64_t(run) * T + t_first) * N + cc[c]] : 0.0;
+                }
+                hcur[c][qi] = v;
+                xq[c * XS + 64 * q + l] = v * il[c][qi];
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < AUXR; ++k2) {
+            const int i = tid + k2 * NT;
+            if (i < 16 * naux) xq[c * XS + 16 * Do + i] = aux_load(c, i, t_first);
+        }
+    }
+    __syncthreads();
+
+    double kregA[RB][4], kregB[RB][4];
+
+    // phase 3 of group c for step index s (time t): epilogue + next input of that group
+    auto phase3 = [&](auto cidx, int s) {
+        constexpr int c = decltype(cidx)::value;
+        const int t = t_first + dir * s;
+        const int tn = t + dir;
+        const bool has_next = (s + 1 < nsteps);
+        const int wq = (c == 0) ? w : (W - 1 - w);
+        const int cch = cc[c];
+        bool resample_n = false;
+        if (MODE == MODE_BWD) resample_n = has_next && (((tn + 1 + run * R) % P) == 0);
+        double eps_t, hidn = 0.0;
+        if (MODE == MODE_FWD) eps_t = a.eps[int64_t(t) * N + cch];
+        else {
+            eps_t = a.eps[(int64_t(run) * T + t) * N + cch];
+            if (resample_n) hidn = a.hid[(int64_t(run) * T + tn) * N + cch];
+        }
+        double auxn[AUXR];
+#pragma unroll
+        for (int k2 = 0; k2 < AUXR; ++k2) {
+            const int i = tid + k2 * NT;
+            auxn[k2] = (has_next && i < 16 * naux) ? aux_load(c, i, tn) : 0.0;
+        }
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int q = wq + qi * W;
+            if (q < 4) {
+                const int d = 4 * q + g;
+                double ytil = 0.0;
+                if (MODE == MODE_FWD && act[c][qi])
+                    ytil = (d < a.dim_y) ? a.y[(int64_t(bqv[c]) * T + (t + 1)) * a.dim_y + d]
+                                         : a.y2_in[(int64_t(t + 1) * N + cch) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
+                double fm, fv;
+                tile.gather(part + c * PS, q, l, fm, fv);
+                double outv = 0.0;
+                if (act[c][qi]) {
+                    const double fmean = fm + hcur[c][qi];
+                    const double fvar = fv + vx[c][qi];
+                    if (MODE == MODE_FWD) {
+                        const double vyt = vy[c][qi] + (a.k_factor - 1.0) * fvar;
+                        const double sm = vyt + fvar;
+                        const double kk = fvar * (1.0 / sm);
+                        const double ydiff = ytil - fmean;
+                        const double mu = fmean + kk * ydiff;
+                        const double omk = 1.0 - kk;
+                        const double sig = omk * omk * fvar + kk * kk * vyt;
+                        const bool do_cond = a.condition || (t < R - 1);
+                        outv = do_cond ? (mu + eps_t * sqrt(sig)) : (fmean + eps_t * sqrt(fvar));
+                        if (do_cond && cval[c]) {
+                            const double rf = 1.0 / fvar;
+                            const double dm = mu - fmean;
+                            lin[c][qi] += (sig + dm * dm) * rf - 1.0;
+                            lp[c][qi].mul(sig * rf);
+                        }
+                        if (cval[c]) a.x_out[(int64_t(t + 1) * N + cch) * a.dim_x + d] = outv;
+                    } else {
+                        outv = fmean + eps_t * sqrt(fvar);
+                        const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
+                        if (cval[c]) {
+                            if (write) {
+                                a.y2_out[(int64_t(t) * N + cch) * Do + d] = outv;
+                                lp[c][qi].mul(fvar);
+                                lin[c][qi] += 1.0;
+                            }
+                            if (a.h_all) a.h_all[((int64_t(run) * T + t) * N + cch) * Do + d] = outv;
+                        }
+                    }
+                }
+                const double hn = (MODE == MODE_BWD && resample_n) ? hidn : outv;
+                hcur[c][qi] = act[c][qi] ? hn : 0.0;
+                if (has_next && act[c][qi]) xq[c * XS + 64 * q + l] = hn * il[c][qi];
+            }
+        }
+        if (has_next) {
+#pragma unroll
+            for (int k2 = 0; k2 < AUXR; ++k2) {
+                const int i = tid + k2 * NT;
+                if (i < 16 * naux) xq[c * XS + 16 * Do + i] = auxn[k2];
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    tile.phase1(xq, Kt, kregA, w, l);                                   // phase1(A, 0)
+    __syncthreads();
+    // SIMD partners (waves w and w+4) run the two halves of an interval in opposite order, so that one is in its
+    // matrix part while the other is in its VALU part
+    const bool hi = (w >= 4);
+    for (int s = 0; s < nsteps; ++s) {
+        // alpha: phase2(A, s) || phase3(B, s-1)   (B's epilogue lanes sit on the high waves)
+        if (hi) {
+            if (s > 0) phase3(I1{}, s - 1);
+            tile.phase2(Kt, part, kregA, w, l);
+        } else {
+            tile.phase2(Kt, part, kregA, w, l);
+            if (s > 0) phase3(I1{}, s - 1);
+        }
+        __syncthreads();
+        // beta: phase1(B, s) || phase3(A, s)      (A's epilogue lanes sit on the low waves)
+        if (hi) {
+            tile.phase1(xq + XS, Kt + KTS, kregB, w, l);
+            phase3(I0{}, s);
+        } else {
+            phase3(I0{}, s);
+            tile.phase1(xq + XS, Kt + KTS, kregB, w, l);
+        }
+        __syncthreads();
+        // gamma: phase2(B, s) || phase1(A, s+1)
+        if (hi) {
+            tile.phase2(Kt + KTS, part + PS, kregB, w, l);
+            if (s + 1 < nsteps) tile.phase1(xq, Kt, kregA, w, l);
+        } else {
+            if (s + 1 < nsteps) tile.phase1(xq, Kt, kregA, w, l);
+            tile.phase2(Kt + KTS, part + PS, kregB, w, l);
+        }
+        __syncthreads();
+    }
+    phase3(I1{}, nsteps - 1);                                           // phase3(B, last)
+
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            if (act[c][qi] && cval[c]) {
+                if (MODE == MODE_FWD) v += 0.5 * (lin[c][qi] - lp[c][qi].log());
+                else v += 0.5 * (lin[c][qi] * 2.8378770664093453391 + lp[c][qi].log());
+            }
+        }
     const double tot = block_sum(v, red, tid, NT);
     if (tid == 0) a.part_out[blockIdx.y * gridDim.x + blockIdx.x] = tot;
 }

@@ -19,7 +19,8 @@ N = w.N
 noise = {'hid_b': torch.randn(2 * w.T * N, dtype=torch.float64, device=dev, generator=g),
          'eps_b': torch.randn(2 * w.T * N, dtype=torch.float64, device=dev, generator=g),
          'eps_f': torch.randn((w.T - 1) * N, dtype=torch.float64, device=dev, generator=g)}
-eng.loss_and_grads(params, u, y, noise)
+for _ in range(int(os.environ.get('REPS', '40'))):
+    eng.loss_and_grads(params, u, y, noise)
 torch.cuda.synchronize()
 ws = eng.last_ws
 names = ['A fill', 'B ktile', 'C a2,P', 'D epi', 'E a2bar,gB', 'F kbar,xp,gZ', 'G carry']
@@ -27,6 +28,7 @@ for tag, slab, nwg, nstep_total in (('fwd-adjoint', eng.red[:eng.slab_f], ws.n_f
                                     ('bwd-adjoint', eng.red[eng.slab_f:eng.slab_f + eng.slab_b], ws.n_b, None)):
     small = slab[-192:].cpu().numpy()
     print(tag, 'workgroups', nwg)
+    print('  in-kernel clock: %.0f MHz (sum over workgroups of cycles / realtime ticks x 100 MHz)' % (100.0 * small[140] / max(small[141], 1.0)))
     for wname, o in (('wave0', 100), ('lastwave', 114)):
         c, wt = small[o:o + 7], small[o + 7:o + 14]
         tot = c.sum() + wt.sum()
