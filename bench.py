@@ -28,9 +28,10 @@ F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (spec); csrc/probe/mfma_f64_p
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(w, seconds_budget=20.0, threads=16):
+def cpu_baseline(w, mode='eval', seconds_budget=25.0, threads=16):
     """The op-for-op PyTorch-CPU float64 restatement (oracle/cbfssm_torch_ref.py) on the host cores, on a bounded
-    sample: the same workload with T truncated (cost is exactly linear in the number of GP calls 3T-1)."""
+    sample: the same workload with T truncated (cost is exactly linear in the number of GP calls 3T-1).  mode=train
+    times loss + reverse-mode gradient (what TF's minimize() executes), mode=eval the loss only."""
     from cbfssm import synthetic as syn
     from oracle import cbfssm_torch_ref as tref
     import dataclasses
@@ -43,20 +44,25 @@ def cpu_baseline(w, seconds_budget=20.0, threads=16):
     noise = {k: torch.tensor(v) for k, v in syn.make_noise(ws).items()}
     times = []
     t_all = time.perf_counter()
-    with torch.no_grad():
-        for i in range(5):
-            t0 = time.perf_counter()
-            tref.elbo_step(cfg, p, u, y, noise, True)
-            times.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_all > seconds_budget and i >= 1:
-                break
+    for i in range(5):
+        t0 = time.perf_counter()
+        if mode == 'train':
+            pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            tref.elbo_step(cfg, pg, u, y, noise, True)['loss'].backward()
+        else:
+            with torch.no_grad():
+                tref.elbo_step(cfg, p, u, y, noise, True)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > seconds_budget and i >= 1:
+            break
     t_sample = float(np.median(times[1:] if len(times) > 1 else times))
     scale = (3 * w.T - 1) / (3 * T_s - 1)
     t_full = t_sample * scale
     return {'value': 1.0 / t_full, 'unit': 'steps/s', 'cores': threads, 'kind': 'port',
-            'sample': 'eval step of %s with T truncated to %d (%d of %d GP calls), median of %d runs = %.3f s, '
-                      'scaled linearly to T=%d; PyTorch-CPU float64 restatement of the TF-1.8 op sequence, %d threads'
-                      % (w.name, T_s, 3 * T_s - 1, 3 * w.T - 1, max(1, len(times) - 1), t_sample, w.T, threads)}
+            'sample': '%s step of %s with T truncated to %d (%d of %d GP calls), median of %d runs = %.3f s, '
+                      'scaled linearly to T=%d; PyTorch-CPU float64 restatement of the TF-1.8 op sequence%s, %d threads'
+                      % (mode, w.name, T_s, 3 * T_s - 1, 3 * w.T - 1, max(1, len(times) - 1), t_sample, w.T,
+                         ' + reverse-mode autodiff' if mode == 'train' else '', threads)}
 
 
 def main():
@@ -148,17 +154,14 @@ def main():
     loss = float(out[6]) if mode == 'eval' else float(out)
     assert np.isfinite(loss), 'non-finite loss'
 
-    # ---- per-kernel timing of the two time-loop kernels with HIP events on the launch stream
+    # ---- per-kernel timing of the time-loop kernels with HIP events on the launch stream
     roof = None
     if rank == 0:
-        eng2 = ops.HipElbo(cfg, dev)
-        eng2.prepare(params)
-        noise = draw_noise()
-        prob = eng2.problem(w.B, w.T, True)
-        ws = ops.ElboWorkspace(prob, dev, keep_h=False)
         import ctypes as C
         l = lib.load()
         st = ops._stream()
+        noise = draw_noise()
+        prob = lib.make_problem(w.B, w.S, w.T, w.dim_x, w.dim_u, w.dim_y, w.M, cfg['recog_len'], cfg['k_factor'], True)
 
         def time_kernel(fn, reps=10):
             fn()
@@ -171,30 +174,68 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e-3 / reps
 
+        if mode == 'train' and not stepper.engine.stash:
+            eng2 = stepper.engine
+            eng2.loss_and_grads(stepper.params, u, y, noise)          # fills the saved trajectories
+            ws = eng2.last_ws
+            cst = eng2._constrained({k: v for k, v in stepper.params.items()})
+            var_x, var_y = cst['var_x'], cst['var_y']
+            pack_f, pack_b = eng2.pack_f, eng2.pack_b
+        else:
+            eng2 = ops.HipElbo(cfg, dev)
+            eng2.prepare(params if mode == 'eval' else stepper.params)
+            ws = ops.ElboWorkspace(prob, dev, keep_h=False)
+            var_x, var_y, pack_f, pack_b = eng2.var_x, eng2.var_y, eng2.pack_f, eng2.pack_b
+
         def k_bwd():
-            lib.check(l.cbfssm_backward_pass_f64(C.byref(prob), C.byref(eng2.pack_b.layout), ops._ptr(eng2.pack_b.buf),
-                                                 ops._ptr(eng2.var_x), ops._ptr(u), ops._ptr(y),
-                                                 ops._ptr(noise['hid_b']), ops._ptr(noise['eps_b']), ops._ptr(ws.y2),
-                                                 None, ops._ptr(ws.ent_part), st), 'bwd')
+            lib.check(l.cbfssm_backward_pass_f64(C.byref(prob), C.byref(pack_b.layout), ops._ptr(pack_b.buf),
+                                                 ops._ptr(var_x), ops._ptr(u), ops._ptr(y), ops._ptr(noise['hid_b']),
+                                                 ops._ptr(noise['eps_b']), ops._ptr(ws.y2), ops._ptr(ws.h_all),
+                                                 ops._ptr(ws.ent_part), st), 'bwd')
 
         def k_fwd():
-            lib.check(l.cbfssm_forward_pass_f64(C.byref(prob), C.byref(eng2.pack_f.layout), ops._ptr(eng2.pack_f.buf),
-                                                ops._ptr(eng2.var_x), ops._ptr(eng2.var_y), ops._ptr(u), ops._ptr(y),
+            lib.check(l.cbfssm_forward_pass_f64(C.byref(prob), C.byref(pack_f.layout), ops._ptr(pack_f.buf),
+                                                ops._ptr(var_x), ops._ptr(var_y), ops._ptr(u), ops._ptr(y),
                                                 ops._ptr(ws.y2), ops._ptr(noise['eps_f']), ops._ptr(ws.x),
                                                 ops._ptr(ws.kl_part), st), 'fwd')
 
         def F(M, D, Do):   # algorithmic FLOPs of one GP point evaluation
             return 2 * M * M + M * (2 * D + 5 * Do + 5)
-        t_b, t_f = time_kernel(k_bwd), time_kernel(k_fwd)
-        fl_b = 2.0 * w.T * N * F(w.M, w.D, w.dim_out_b)
-        fl_f = 1.0 * (w.T - 1) * N * F(w.M, w.D, w.dim_x)
-        name, tk, fl = ('backward_pass (pass_kernel MODE_BWD)', t_b, fl_b) if t_b >= t_f else \
-                       ('forward_pass (pass_kernel MODE_FWD)', t_f, fl_f)
+        kern = {}
+        k_bwd(); k_fwd()
+        kern['backward_pass'] = (time_kernel(k_bwd), 2.0 * w.T * N * F(w.M, w.D, w.dim_out_b))
+        kern['forward_pass'] = (time_kernel(k_fwd), 1.0 * (w.T - 1) * N * F(w.M, w.D, w.dim_x))
+        if mode == 'train' and not stepper.engine.stash:
+            cL, cE = float(cfg['loss_factors'][0]) / w.S, float(cfg['loss_factors'][1]) / w.S
+
+            def k_rfwd():
+                lib.check(l.cbfssm_forward_pass_bwd_f64(C.byref(prob), C.byref(pack_f.layout), ops._ptr(pack_f.buf),
+                                                        ops._ptr(var_x), ops._ptr(var_y), ops._ptr(u), ops._ptr(y),
+                                                        ops._ptr(ws.y2), ops._ptr(noise['eps_f']), ops._ptr(ws.x), cL,
+                                                        ops._ptr(ws.gy2), ops._ptr(ws.gpart_f), st), 'rev fwd')
+
+            def k_rbwd():
+                lib.check(l.cbfssm_backward_pass_bwd_f64(C.byref(prob), C.byref(pack_b.layout), ops._ptr(pack_b.buf),
+                                                         ops._ptr(var_x), ops._ptr(u), ops._ptr(y),
+                                                         ops._ptr(noise['hid_b']), ops._ptr(noise['eps_b']),
+                                                         ops._ptr(ws.h_all), ops._ptr(ws.gy2), cE, ops._ptr(ws.gpart_b),
+                                                         st), 'rev bwd')
+            # adjoint of one GP evaluation: recompute (F) + reverse sweep (2F)  
+            kern['forward_pass_adjoint'] = (time_kernel(k_rfwd, 5), 3.0 * (w.T - 1) * N * F(w.M, w.D, w.dim_x))
+            kern['backward_pass_adjoint'] = (time_kernel(k_rbwd, 5), 6.0 * w.T * N * F(w.M, w.D, w.dim_out_b))
+        name = max(kern, key=lambda k: kern[k][0])
+        tk, fl = kern[name]
         ach = fl / tk / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic.json')
+        if os.path.exists(tpath):
+            # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/tools/collect_traffic.sh)
+            tj = json.load(open(tpath))
+            traffic = tj.get(args.workload, {}).get(name)
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': None, 'kernel': name,
-                'kernel_ms': {'backward_pass': t_b * 1e3, 'forward_pass': t_f * 1e3},
-                'kernel_tflops': {'backward_pass': fl_b / t_b / 1e12, 'forward_pass': fl_f / t_f / 1e12},
+                'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'kernel': name,
+                'kernel_ms': {k: v[0] * 1e3 for k, v in kern.items()},
+                'kernel_tflops': {k: v[1] / v[0] / 1e12 for k, v in kern.items()},
                 'hbm_algorithmic_GBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9,
                 'hbm_frac_of_8TBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
 
@@ -214,9 +255,7 @@ def main():
             'roofline': roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            rec['cpu_baseline'] = cpu_baseline(w)
-            if mode == 'train':
-                rec['cpu_baseline']['sample'] += ' (eval step; a train step costs ~3x on either side)'
+            rec['cpu_baseline'] = cpu_baseline(w, mode)
             rec['speedup_vs_cpu_baseline'] = rec['value'] / rec['cpu_baseline']['value']
         else:
             rec['cpu_baseline'] = None

@@ -1,0 +1,12 @@
+#!/bin/bash
+# HBM traffic of the hot-path kernels from rocprofv3 PMC counters (MI355X_MICROARCH.md, section HBM):
+# FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots), both are in KiB.  Run on the GPU box from the repo root:
+#   bash profiles/tools/collect_traffic.sh C3 gpurun_out/traffic
+set -e
+WL=${1:-C3}
+OUT=${2:-gpurun_out/traffic}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$OUT/fetch -- python3 $R/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline > $R/$OUT.fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$OUT/write -- python3 $R/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline > $R/$OUT.write.log 2>&1
+python3 $R/profiles/tools/pmc_summary.py $R/$OUT/fetch $R/$OUT/write
