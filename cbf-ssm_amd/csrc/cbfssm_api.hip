@@ -82,6 +82,7 @@ struct PrepArgs2 {
 // and is swept column by column (right-looking Cholesky of [[K, I],[I, *]] restricted to the blocks that are needed):
 // afterwards column j of the lower part is L[:,j] * sqrt(piv_j) and row i of the strict upper part is
 // L^-T[i,:] * sqrt(piv) (unit diagonal implied).  One barrier per column.
+template <bool LDSW>
 __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
 {
     const PrepArgs& a = aa.g[blockIdx.x];
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
     const int tid = threadIdx.x;
     const int M = a.M, D = a.D;
     const int LD = M | 1;
-    double* Wm = (a.gmat != nullptr) ? a.gmat : smem;
+    // (a compile-time choice keeps the address space known: ds_read/ds_write instead of flat accesses)
+    double* Wm;
+    if constexpr (LDSW) Wm = smem; else Wm = a.gmat;
     const int tx = tid & 31, ty = tid >> 5;   // 32 x 32 thread tile
 
     if (tid == 0) s_info = 0;
@@ -233,12 +236,16 @@ static int launch_prepare(PrepArgs2& aa, int n, int maxM, hipStream_t st)
 {
     size_t lds = 0;
     if (maxM <= PREP_LDS_MAX_M) lds = size_t(maxM | 1) * maxM * sizeof(double);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prepare_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return fail(-int(e) - 1000, "prepare: %s", hipGetErrorString(e));
+    if (lds > 0) {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prepare_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (e != hipSuccess) return fail(-int(e) - 1000, "prepare: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(prepare_kernel<true>, dim3(n), dim3(PREP_NT), lds, st, aa);
+    } else {
+        hipLaunchKernelGGL(prepare_kernel<false>, dim3(n), dim3(PREP_NT), 0, st, aa);
     }
-    hipLaunchKernelGGL(prepare_kernel, dim3(n), dim3(PREP_NT), lds, st, aa);
     return check_launch("gp_prepare");
 }
 
