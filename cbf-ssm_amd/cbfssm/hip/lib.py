@@ -19,7 +19,7 @@ SYMBOLS = (
     'cbfssm_forward_pass_partials', 'cbfssm_forward_pass_f64', 'cbfssm_loglik_moments_f64',
     'cbfssm_elbo_combine_f64', 'cbfssm_rev_workgroups', 'cbfssm_forward_pass_bwd_f64',
     'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64', 'cbfssm_bwd_segments', 'cbfssm_forward_pass_bwd_ex_f64',
-    'cbfssm_backward_pass_bwd_ex_f64',
+    'cbfssm_backward_pass_bwd_ex_f64', 'cbfssm_half_forward_pass_f64', 'cbfssm_half_forward_pass_bwd_f64',
 )
 
 
@@ -31,7 +31,7 @@ class PackLayout(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('B', 'S', 'T', 'dim_x', 'dim_u', 'dim_y', 'M', 'recog_len', 'condition',
-                                          'pad_')] + [('k_factor', C.c_double)]
+                                          'half')] + [('k_factor', C.c_double)]
 
 
 class CbfssmHipError(RuntimeError):
@@ -74,6 +74,8 @@ def load():
     lib.cbfssm_bwd_segments.argtypes = [C.POINTER(Problem)]
     lib.cbfssm_forward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, vp, ip, ip, vp, vp, vp, i64, vp])
     lib.cbfssm_backward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, ip, ip, ip, vp, vp, i64, vp])
+    lib.cbfssm_half_forward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10
+    lib.cbfssm_half_forward_pass_bwd_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 7 + [dbl, vp, vp, ip, ip, vp, vp, vp, i64, vp])
     lib.cbfssm_reduce_partials_f64.argtypes = [vp, i64, i64, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
@@ -95,8 +97,8 @@ def pack_layout(M, D, Do):
     return lay
 
 
-def make_problem(B, S, T, dim_x, dim_u, dim_y, M, recog_len, k_factor, condition):
+def make_problem(B, S, T, dim_x, dim_u, dim_y, M, recog_len, k_factor, condition, half=False):
     p = Problem()
     p.B, p.S, p.T, p.dim_x, p.dim_u, p.dim_y, p.M = int(B), int(S), int(T), int(dim_x), int(dim_u), int(dim_y), int(M)
-    p.recog_len, p.condition, p.pad_, p.k_factor = int(recog_len), int(bool(condition)), 0, float(k_factor)
+    p.recog_len, p.condition, p.half, p.k_factor = int(recog_len), int(bool(condition)), int(bool(half)), float(k_factor)
     return p

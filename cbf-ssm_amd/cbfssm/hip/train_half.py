@@ -1,0 +1,256 @@
+"""CBFSSMHALF on the HIP path (reference cbfssm/model/cbfssmhalf.py): forward-only variant -- x_0 comes from a
+recognition model, the Kalman-style update acts on the observed state dims only, the ELBO has no backward GP and no
+entropy term (cbfssmhalf.py:174-199).
+
+The time loop and its adjoint run in the same kernels as CBFSSM's forward pass (problem.half = 1,
+include/cbfssm_hip.h: cbfssm_half_forward_pass_f64 / _bwd_f64).  The recognition model is a GRU(16) over
+recog_len steps + a dense layer on B sequences (cbfssmhalf.py:82-93) -- a few hundred FLOPs per sequence; it stays in
+PyTorch autograd (float64, TF-1.8 GRUCell gate layout) and receives d loss / d x_0 from the adjoint kernel.
+"""
+import ctypes as C
+import math
+import torch
+
+from . import lib as _l
+from . import ops
+from .ops import _ptr, _stream, _f64, tf_forward, GPPack
+from .dist_utils import all_reduce_sum
+from .train import HipElboGrad, LOG2PI
+
+GP_NAMES = ('f.zeta_pos', 'f.zeta_mean', 'f.zeta_var_unc', 'f.variance_unc', 'f.lengthscales_unc')
+RECOG_NAMES = ('recog.gate_kernel', 'recog.gate_bias', 'recog.cand_kernel', 'recog.cand_bias', 'recog.dense_kernel',
+               'recog.dense_bias')
+GRU_UNITS = 16      # cbfssmhalf.py:84
+
+
+def half_param_names(config):
+    names = GP_NAMES + ('var_x_unc', 'var_y_unc')
+    if config.get('recog_model', 'rnn') == 'rnn':
+        names = names + RECOG_NAMES
+    return names
+
+
+def gru_recognition(recog, u, y, recog_len):
+    """TF-1.8 GRUCell(16) over the reversed first recog_len steps of [u, y], then dense -> dim_x (cbfssmhalf.py:82-93)."""
+    uy = torch.flip(torch.cat((u, y), dim=2)[:, :recog_len, :], dims=[1])
+    h = torch.zeros(u.shape[0], GRU_UNITS, dtype=u.dtype, device=u.device)
+    for t in range(uy.shape[1]):
+        x = uy[:, t, :]
+        gates = torch.sigmoid(torch.cat((x, h), 1) @ recog['recog.gate_kernel'] + recog['recog.gate_bias'])
+        r, z = torch.chunk(gates, 2, dim=1)
+        c = torch.tanh(torch.cat((x, r * h), 1) @ recog['recog.cand_kernel'] + recog['recog.cand_bias'])
+        h = z * h + (1.0 - z) * c
+    return h @ recog['recog.dense_kernel'] + recog['recog.dense_bias']
+
+
+class HipHalfGrad:
+    """loss and gradients of CBFSSMHALF for one mini-batch on one device."""
+
+    def __init__(self, config, device, dist=None):
+        self.config = config
+        self.device = torch.device(device)
+        self.dist = dist
+        self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
+        self.M, self.S = config['ind_pnt_num'], config['samples']
+        self.D = self.dim_x + self.dim_u
+        self.names = half_param_names(config)
+        self.rnn = 'recog.gate_kernel' in self.names
+        self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device)
+        self.stash = bool(self.pack_f.layout.rev_stash)
+        self.stash_bytes = int(float(config.get('adjoint_stash_gib', 4.0)) * 2 ** 30)
+        self._stash_buf = None
+        self.slab_f = int(self.pack_f.layout.rev_slab)
+        self._ws = {}
+        self.last_ws = None
+        # the K_mm / Cholesky / prior-KL adjoint is shared with CBFSSM
+        self._gp_adjoint = HipElboGrad._gp_adjoint.__get__(self)
+
+    def _problem(self, B, T, condition):
+        c = self.config
+        return _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, c['recog_len'], c['k_factor'],
+                               condition, half=True)
+
+    def _x0(self, p, u, y):
+        if self.rnn:
+            return gru_recognition(p, u, y, self.config['recog_len'])
+        B = u.shape[0]
+        return torch.cat((y[:, 0, :], torch.zeros(B, self.dim_x - self.dim_y, dtype=u.dtype, device=u.device)), dim=1)
+
+    def _forward(self, p, c, x0, u, y, eps_f, prob, ws):
+        lib = _l.load()
+        st = _stream()
+        pb = C.byref(prob)
+        self.pack_f.prepare(p['f.zeta_pos'], c['ls'], c['var'], p['f.zeta_mean'], c['zvar'])
+        lay = C.byref(self.pack_f.layout)
+        rc = lib.cbfssm_half_forward_pass_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
+                                              _ptr(u), _ptr(y), _ptr(x0), _ptr(eps_f) if eps_f.numel() else None,
+                                              _ptr(ws.x), _ptr(ws.kl_part), st)
+        _l.check(rc, 'cbfssm_half_forward_pass_f64')
+        rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(c['var_y']), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part),
+                                           _ptr(ws.pred_mean), _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)
+        _l.check(rc, 'cbfssm_loglik_moments_f64')
+        lf = self.config['loss_factors']
+        rc = lib.cbfssm_elbo_combine_f64(pb, float(lf[0]), 0.0, _ptr(ws.ll_part), ws.ll_part.numel(), _ptr(ws.kl_part),
+                                         ws.kl_part.numel(), None, 0, _ptr(self.pack_f.scal), None, _ptr(ws.out), st)
+        _l.check(rc, 'cbfssm_elbo_combine_f64')
+
+    def _constrained(self, p):
+        return {'ls': tf_forward(p['f.lengthscales_unc']).reshape(-1).contiguous(),
+                'var': tf_forward(p['f.variance_unc']).reshape(-1).contiguous(),
+                'zvar': tf_forward(p['f.zeta_var_unc']).contiguous(),
+                'var_x': tf_forward(p['var_x_unc']).contiguous(), 'var_y': tf_forward(p['var_y_unc']).contiguous()}
+
+    def _workspace(self, prob):
+        key = (prob.B, prob.T)
+        if key not in self._ws:
+            lib = _l.load()
+            f = dict(dtype=torch.float64, device=self.device)
+            N = prob.B * prob.S
+
+            class WS:
+                pass
+            ws = WS()
+            ws.n_kl = int(lib.cbfssm_forward_pass_partials(C.byref(prob)))
+            ws.n_f = int(lib.cbfssm_rev_workgroups(C.byref(prob), 0))
+            ws.x = torch.zeros(prob.T, N, prob.dim_x, **f)
+            ws.kl_part = torch.zeros(ws.n_kl, **f)
+            ws.ll_part = torch.zeros(prob.B * prob.T * prob.dim_y, **f)
+            ws.pred_mean = torch.zeros(prob.B, prob.T, prob.dim_y, **f)
+            ws.pred_var = torch.zeros(prob.B, prob.T, prob.dim_y, **f)
+            ws.int_mean = torch.zeros(prob.B, prob.T, prob.dim_x, **f)
+            ws.int_var = torch.zeros(prob.B, prob.T, prob.dim_x, **f)
+            ws.out = torch.zeros(8, **f)
+            ws.y2 = torch.zeros(prob.T, N, max(0, prob.dim_x - prob.dim_y), **f)      # (surface compatibility)
+            ws.gx0 = torch.zeros(N, prob.dim_x, **f)
+            ws.gx_carry = torch.zeros(N, prob.dim_x, **f)
+            ws.gpart_f = torch.zeros((ws.n_f + 32) * self.slab_f, **f)
+            ws.red = torch.zeros(self.slab_f + 2 + prob.dim_y, **f)
+            self._ws[key] = ws
+        return self._ws[key]
+
+    def _terms(self, ws, red2=None):
+        out = ws.out
+        lf = self.config['loss_factors']
+        cL = float(lf[0]) / self.S
+        if red2 is None:
+            loglik, kl_x = out[0], out[1]
+        else:
+            loglik, kl_x = red2[0], red2[1]
+        loss = -(loglik * cL - kl_x * cL - out[3])                                 # cbfssmhalf.py:195-199
+        z = torch.zeros((), dtype=torch.float64, device=self.device)
+        return loss, {'loglik': loglik, 'kl_x': kl_x, 'entropy': z, 'kl_z_f': out[3], 'kl_z_b': z, 'info': out[7]}
+
+    def forward(self, params, u, y, noise, condition=True):
+        dev = self.device
+        p = {k: _f64(params[k], dev) for k in self.names}
+        u, y = _f64(u, dev), _f64(y, dev)
+        prob = self._problem(u.shape[0], u.shape[1], condition)
+        ws = self._workspace(prob)
+        with torch.no_grad():
+            x0 = self._x0(p, u, y).contiguous()
+        self._forward(p, self._constrained(p), x0, u, y, _f64(noise['eps_f'], dev), prob, ws)
+        self.last_ws = ws
+        red2 = None
+        if self.dist is not None:
+            red2 = ws.out[0:2].clone()
+            all_reduce_sum(red2, self.dist)
+        loss, terms = self._terms(ws, red2)
+        return loss, terms, ws
+
+    def loss_and_grads(self, params, u, y, noise, condition=True):
+        lib = _l.load()
+        dev = self.device
+        p = {k: _f64(params[k], dev) for k in self.names}
+        u, y = _f64(u, dev), _f64(y, dev)
+        B, T = u.shape[0], u.shape[1]
+        prob = self._problem(B, T, condition)
+        ws = self._workspace(prob)
+        self.last_ws = ws
+        c = self._constrained(p)
+        eps_f = _f64(noise['eps_f'], dev)
+        rp = {}
+        if self.rnn:
+            rp = {k: p[k].detach().clone().requires_grad_(True) for k in RECOG_NAMES}
+            x0g = gru_recognition(rp, u, y, self.config['recog_len'])
+            x0 = x0g.detach().contiguous()
+        else:
+            x0 = self._x0(p, u, y).contiguous()
+        self._forward(p, c, x0, u, y, eps_f, prob, ws)
+
+        st = _stream()
+        pb = C.byref(prob)
+        lf = self.config['loss_factors']
+        cL = float(lf[0]) / self.S
+        sf = self.slab_f
+        red = ws.red
+        lay = C.byref(self.pack_f.layout)
+        N = B * self.S
+        groups = (N + 15) // 16
+        gB = None
+        if not self.stash:
+            rc = lib.cbfssm_half_forward_pass_bwd_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
+                                                      _ptr(u), _ptr(y), _ptr(eps_f) if eps_f.numel() else None,
+                                                      _ptr(ws.x), cL, _ptr(ws.gx0), _ptr(ws.gpart_f), T - 2, 0, None,
+                                                      None, None, 0, st)
+            _l.check(rc, 'cbfssm_half_forward_pass_bwd_f64')
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
+        else:
+            Mp = self.pack_f.layout.Mp
+            cols_max = max(groups * 16, self.stash_bytes // (2 * Mp * 8))
+            f = dict(dtype=torch.float64, device=dev)
+            if self._stash_buf is None or self._stash_buf[0].numel() < Mp * cols_max:
+                self._stash_buf = (torch.zeros(Mp * cols_max, **f), torch.zeros(Mp * cols_max, **f))
+            sa, sk = self._stash_buf
+            gB = torch.zeros(Mp, Mp, **f)
+            tmp = torch.zeros(sf, **f)
+            red[:sf].zero_()
+            per = max(1, cols_max // (groups * 16))
+            t_hi = T - 2
+            while True:
+                t_lo = max(0, t_hi - per + 1)
+                cols = groups * max(0, t_hi - t_lo + 1) * 16
+                rc = lib.cbfssm_half_forward_pass_bwd_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']),
+                                                          _ptr(c['var_y']), _ptr(u), _ptr(y),
+                                                          _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), cL,
+                                                          _ptr(ws.gx0), _ptr(ws.gpart_f), t_hi, t_lo, _ptr(ws.gx_carry),
+                                                          _ptr(sa), _ptr(sk), cols, st)
+                _l.check(rc, 'cbfssm_half_forward_pass_bwd_f64')
+                _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp), st), 'reduce f')
+                red[:sf] += tmp
+                if cols:
+                    gB.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
+                t_hi = t_lo - 1
+                if t_hi < 0:
+                    break
+
+        # log-likelihood's pull on var_y (cbfssmhalf.py:181-189)
+        vy = c['var_y']
+        ll_d = ws.ll_part.view(B * T, self.dim_y).sum(0)
+        sq_d = (-2.0 * ll_d - B * T * self.S * (LOG2PI + torch.log(vy))) * vy
+        tail = red[sf:]
+        tail[0:2] = ws.out[0:2]
+        tail[2:] = -cL * 0.5 * (sq_d / (vy * vy) - B * T * self.S / vy)
+        gx0_b = ws.gx0.view(B, self.S, self.dim_x).sum(1)        # d loss / d x_0 per sequence (tiled over S, :87)
+        rgrads = {}
+        if self.rnn:
+            gl = torch.autograd.grad(x0g, [rp[k] for k in RECOG_NAMES], grad_outputs=gx0_b)
+            rgrads = dict(zip(RECOG_NAMES, gl))
+        if self.dist is not None:
+            all_reduce_sum(red, self.dist)
+            if gB is not None:
+                all_reduce_sum(gB, self.dist)
+            for k in rgrads:
+                all_reduce_sum(rgrads[k], self.dist)
+
+        grads = dict(rgrads)
+        gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(self.pack_f, red[:sf], p['f.zeta_pos'], c['ls'], c['var'],
+                                                          p['f.zeta_mean'], c['zvar'], self.dim_x, gB)
+        grads['f.zeta_pos'] = gz
+        grads['f.zeta_mean'] = gmu
+        grads['f.zeta_var_unc'] = gs2 * torch.sigmoid(p['f.zeta_var_unc'])
+        grads['f.variance_unc'] = (gvar * torch.sigmoid(p['f.variance_unc'])).reshape(p['f.variance_unc'].shape)
+        grads['f.lengthscales_unc'] = gls * torch.sigmoid(p['f.lengthscales_unc'])
+        grads['var_x_unc'] = small[0:self.dim_x] * torch.sigmoid(p['var_x_unc'])
+        grads['var_y_unc'] = (small[16:16 + self.dim_y] + tail[2:]) * torch.sigmoid(p['var_y_unc'])
+        loss, terms = self._terms(ws, tail[0:2])
+        return loss, grads, terms

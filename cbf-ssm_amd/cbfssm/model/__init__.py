@@ -1,8 +1,10 @@
 """cbfssm.model: the CBF-SSM model class on the MI355X HIP path.
 
-The reference also ships CBFSSMHALF, PRSSM and Voliro (cbfssm/model/__init__.py:1-4); they are outside the hot path
-this build accelerates and raise a clear error instead of silently falling back."""
+CBFSSM and its forward-only variant CBFSSMHALF run on the HIP kernels.  The reference also ships PRSSM and Voliro
+(cbfssm/model/__init__.py:3-4); they are outside the hot path this build accelerates and raise
+a clear error instead of silently falling back."""
 from .cbfssm import CBFSSM
+from .cbfssmhalf import CBFSSMHALF
 from .session import Session, OutOfRangeError, InvalidArgumentError
 
 
@@ -15,6 +17,5 @@ def _not_built(name):
     return _Missing
 
 
-CBFSSMHALF = _not_built('CBFSSMHALF')
 PRSSM = _not_built('PRSSM')
 Voliro = _not_built('Voliro')

@@ -76,7 +76,7 @@ class CBFSSM(BaseModel):
     def _ensure(self, sess):
         if self._engine is not None:
             return
-        from ..hip.train import HipElboGrad, TFAdam, PARAM_NAMES
+        from ..hip.train import TFAdam
         dist = None
         try:
             import torch.distributed as td
@@ -86,8 +86,8 @@ class CBFSSM(BaseModel):
             pass
         self._dist = dist
         self._device = sess.device
-        self._engine = HipElboGrad(self.config, sess.device, dist, require_adjoint=False)
-        params = {k: torch.tensor(self._init_values[k], device=sess.device) for k in PARAM_NAMES}
+        self._engine, names = self._make_engine(sess, dist)
+        params = {k: torch.tensor(self._init_values[k], device=sess.device) for k in names}
         self._opt = TFAdam(params, self.config['learning_rate'])                                      # cbfssm.py:274
         self._gen = torch.Generator(device=sess.device)
         seed = self.config.get('seed', None)
@@ -101,6 +101,10 @@ class CBFSSM(BaseModel):
             self._gen.manual_seed(seed + 7919 * (self._rank + 1))
         else:
             self._gen.manual_seed(seed)
+
+    def _make_engine(self, sess, dist):
+        from ..hip.train import HipElboGrad, PARAM_NAMES
+        return HipElboGrad(self.config, sess.device, dist, require_adjoint=False), PARAM_NAMES
 
     def _state_dict(self):
         sd = self._opt.state_dict()

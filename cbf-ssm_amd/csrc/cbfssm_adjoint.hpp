@@ -58,6 +58,8 @@ struct RevArgs {
     double* stash_k;
     int64_t stash_ld;
     int chunk_steps;
+    int half;              // CBFSSMHALF forward pass
+    double* gx0;           // half: (N, dim_x) d loss / d x_0 per chain (summed over the particles by the caller)
 };
 
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         act[qi] = (q < 4) && (d < Do);
         const int dc = act[qi] ? d : 0;
         vx[qi] = a.var_x[dc];
-        vy[qi] = (MODE == MODE_FWD) ? a.var_y[dc] : 0.0;
+        vy[qi] = (MODE == MODE_FWD) ? a.var_y[(a.half && dc >= a.dim_y) ? 0 : dc] : 0.0;
         il[qi] = a.pk.invl[dc];
         gcar[qi] = 0.0; gdir[qi] = 0.0; gvx[qi] = 0.0; gvy[qi] = 0.0;
     }
@@ -259,9 +261,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             for (int qi = 0; qi < QPW; ++qi) {
                 const int d = 4 * (w + qi * W) + g;
                 ytil[qi] = 0.0;
-                if (act[qi])
-                    ytil[qi] = (d < a.dim_y) ? a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d]
-                                             : a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)];
+                if (act[qi]) {
+                    if (d < a.dim_y) ytil[qi] = a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d];
+                    else if (!a.half) ytil[qi] = a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)];
+                }
             }
         } else {
             eps_t = a.eps[(int64_t(run) * T + t) * N + c];
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                     const double fvar = fv + vx[qi];
                     const double gout = gcar[qi];
                     if (MODE == MODE_FWD) {
-                        const bool do_cond = a.condition || (t < R - 1);                       // cbfssm.py:227
+                        const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // cbfssm.py:227
                         if (do_cond) {
                             const double kf1 = a.k_factor - 1.0;
                             const double vyt = vy[qi] + kf1 * fvar;
@@ -408,12 +411,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                             gfv += gs;
                             gvy[qi] += gvyt;
                             gfv += kf1 * gvyt;
-                            if (d >= a.dim_y) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = gyt;
+                            if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = gyt;
                         } else {
                             // x' = fmean + eps sqrt(fvar), no KL term                           (cbfssm.py:224,234)
                             gfm = gout;
                             gfv = gout * eps_t * 0.5 / sqrt(fvar);
-                            if (d >= a.dim_y) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
+                            if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
                         }
                     } else {
                         // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
@@ -623,11 +626,14 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                                 // gin = d loss/d x_t ; add the log-likelihood's own term for x_t (t >= 1)
                                 const int d = 4 * q + g;
                                 if (act[qi] && cvalid) {
-                                    if (t >= 1 && d < a.dim_y) {
+                                    if ((t >= 1 || a.half) && d < a.dim_y) {
                                         const double yv = a.y[(int64_t(bq) * T + t) * a.dim_y + d];
                                         gin += -a.cL * (yv - hcur[qi]) / vy[qi];
                                     }
-                                    if (t == 0 && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = gin;   // x_0 = y_tilde_0
+                                    if (t == 0) {
+                                        if (a.half) a.gx0[int64_t(c) * a.dim_x + d] = gin;       // x_0 = recognition model
+                                        else if (d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = gin;   // x_0 = y_tilde_0
+                                    }
                                 }
                                 gcar[qi] = gin;
                             } else {
@@ -648,7 +654,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) {
                 const int d = 4 * (w + qi * W) + g;
-                if (act[qi] && cvalid && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = 0.0;
+                if (act[qi] && cvalid) {
+                    if (a.half) {
+                        double gv = 0.0;
+                        if (d < a.dim_y) gv = -a.cL * (a.y[(int64_t(bq) * T) * a.dim_y + d] - a.x[int64_t(c) * a.dim_x + d]) / vy[qi];
+                        a.gx0[int64_t(c) * a.dim_x + d] = gv;
+                    } else if (d >= a.dim_y) {
+                        a.gy2[int64_t(c) * dob + (d - a.dim_y)] = 0.0;
+                    }
+                }
             }
         }
         if (a.gx_carry && a.t_lo > 0 && nsteps > 0) {

@@ -319,13 +319,13 @@ __global__ __launch_bounds__(1024) void combine_kernel(CombineArgs a)
     const double kl_x = block_sum(s1, red, tid, 1024);
     const double entropy = block_sum(s2, red, tid, 1024);
     if (tid == 0) {
-        const double klf = a.scal_f[CBFSSM_SCAL_KLZ], klb = a.scal_b[CBFSSM_SCAL_KLZ];
+        const double klf = a.scal_f[CBFSSM_SCAL_KLZ], klb = a.scal_b ? a.scal_b[CBFSSM_SCAL_KLZ] : 0.0;
         // cbfssm.py:257-262
         const double elbo = loglik * a.lambda0 * a.inv_s - kl_x * a.lambda0 * a.inv_s + entropy * a.lambda1 * a.inv_s
                             - klf - klb;
         a.out[0] = loglik; a.out[1] = kl_x; a.out[2] = entropy; a.out[3] = klf; a.out[4] = klb;
         a.out[5] = elbo; a.out[6] = -elbo;
-        a.out[7] = fmax(a.scal_f[CBFSSM_SCAL_INFO], a.scal_b[CBFSSM_SCAL_INFO]);
+        a.out[7] = fmax(a.scal_f[CBFSSM_SCAL_INFO], a.scal_b ? a.scal_b[CBFSSM_SCAL_INFO] : 0.0);
     }
 }
 
@@ -436,11 +436,11 @@ static int pass_nc(const cbfssm_problem* p, int mode)
     if (p->M > 112) return 1;     // two column blocks of the larger tiles do not fit the LDS
     const int64_t n = int64_t(p->B) * p->S;
     const char* e = getenv(mode == MODE_FWD ? "CBFSSM_NC_FWD" : "CBFSSM_NC_BWD");
-    if (e) return atoi(e) == 2 ? 2 : 1;
+    if (e && !p->half) return atoi(e) == 2 ? 2 : 1;
     // measured at C3: the skewed two-group kernel is 3 % faster on the many-workgroup backward runs and 2 % slower
     // on the forward pass (320 -> 160 workgroups)
     if (mode == MODE_BWD) return n >= 32 * 128 ? 2 : 1;
-    return 1;
+    return 1;   // (also required by half mode: only the one-group kernel knows x0)
 }
 
 static void bwd_segments(const cbfssm_problem* p, int* nseg0, int* nseg1)
@@ -611,14 +611,15 @@ int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p)
     return (int64_t(p->B) * p->S + 16 * nc - 1) / (16 * nc);
 }
 
-int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
-                            const double* var_x, const double* var_y, const double* u, const double* y,
-                            const double* y2, const double* eps_f, double* x, double* kl_part, void* stream)
+static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                             const double* var_x, const double* var_y, const double* u, const double* y,
+                             const double* y2, const double* x0, const double* eps_f, double* x, double* kl_part,
+                             void* stream)
 {
     int rc = check_problem(p, L, p ? p->dim_x : 0);
     if (rc) return rc;
     if (!pack_f || !var_x || !var_y || !u || !y || !x || !kl_part) return fail(-1, "null pointer");
-    if (p->dim_x > p->dim_y && !y2) return fail(-1, "y2 is null");
+    if (p->half ? !x0 : (p->dim_x > p->dim_y && !y2)) return fail(-1, p->half ? "x0 is null" : "y2 is null");
     if (p->T > 1 && !eps_f) return fail(-1, "eps_f is null");
     PassArgs a;
     memset(&a, 0, sizeof(a));
@@ -629,11 +630,28 @@ int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L
     a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x;
     a.part_out = kl_part;
     a.dbg = g_dbg;
+    a.half = p->half; a.x0 = x0;
     const int nc = pass_nc(p, MODE_FWD);
     dim3 grid(unsigned((a.N + 16 * nc - 1) / (16 * nc)), 1);
     rc = dispatch_pass(L->NBLK, L->DK, MODE_FWD, a, grid, nc, (hipStream_t)stream);
     if (rc) return fail(rc, "forward_pass launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
+}
+
+int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                            const double* var_x, const double* var_y, const double* u, const double* y,
+                            const double* y2, const double* eps_f, double* x, double* kl_part, void* stream)
+{
+    if (p && p->half) return fail(-1, "problem->half is set: use cbfssm_half_forward_pass_f64");
+    return forward_pass_impl(p, L, pack_f, var_x, var_y, u, y, y2, nullptr, eps_f, x, kl_part, stream);
+}
+
+int cbfssm_half_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                                 const double* var_x, const double* var_y, const double* u, const double* y,
+                                 const double* x0, const double* eps_f, double* x, double* kl_part, void* stream)
+{
+    if (!p || !p->half) return fail(-1, "problem->half must be 1");
+    return forward_pass_impl(p, L, pack_f, var_x, var_y, u, y, nullptr, x0, eps_f, x, kl_part, stream);
 }
 
 int cbfssm_loglik_moments_f64(const cbfssm_problem* p, const double* var_y, const double* y, const double* x,
@@ -656,7 +674,7 @@ int cbfssm_elbo_combine_f64(const cbfssm_problem* p, double lambda0, double lamb
                             int64_t n_ll, const double* kl_part, int64_t n_kl, const double* ent_part, int64_t n_ent,
                             const double* scal_f, const double* scal_b, double* out, void* stream)
 {
-    if (!p || !scal_f || !scal_b || !out) return fail(-1, "null pointer");
+    if (!p || !scal_f || !out) return fail(-1, "null pointer");   // scal_b may be null (CBFSSMHALF has no gp_b)
     CombineArgs a;
     a.ll = ll_part; a.n_ll = ll_part ? n_ll : 0; a.kl = kl_part; a.n_kl = kl_part ? n_kl : 0;
     a.ent = ent_part; a.n_ent = ent_part ? n_ent : 0;
@@ -722,16 +740,16 @@ static int set_stash(RevArgs& a, const cbfssm_pack_layout* L, double* stash_a, d
     return 0;
 }
 
-int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
-                                   const double* var_x, const double* var_y, const double* u, const double* y,
-                                   const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
-                                   double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
-                                   double* stash_k, int64_t stash_ld, void* stream)
+static int forward_pass_bwd_impl(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                                 const double* var_x, const double* var_y, const double* u, const double* y,
+                                 const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
+                                 double* gx0, double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
+                                 double* stash_k, int64_t stash_ld, void* stream)
 {
     int rc = check_problem(p, L, p ? p->dim_x : 0);
     if (rc) return rc;
     if (!pack_f || !var_x || !var_y || !u || !y || !x || !gpart) return fail(-1, "null pointer");
-    if (p->dim_x > p->dim_y && (!y2 || !gy2)) return fail(-1, "y2/gy2 is null");
+    if (p->half ? !gx0 : (p->dim_x > p->dim_y && (!y2 || !gy2))) return fail(-1, "y2/gy2/gx0 is null");
     if (p->T > 1 && !eps_f) return fail(-1, "eps_f is null");
     if (t_hi > p->T - 2 || t_lo < 0) return fail(-1, "bad step range [%d, %d]", t_lo, t_hi);
     if ((t_hi < p->T - 2 || t_lo > 0) && t_hi >= t_lo && !gx_carry) return fail(-1, "partial range needs gx_carry");
@@ -740,6 +758,7 @@ int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_la
     if (rc) return rc;
     a.cL = cL; a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.x = x; a.y2 = y2; a.gy2 = gy2;
     a.gpart = gpart; a.t_hi = t_hi; a.t_lo = t_lo; a.gx_carry = gx_carry;
+    a.half = p->half; a.gx0 = gx0;
     const int64_t groups = (a.N + 15) / 16;
     const int steps = t_hi >= t_lo ? t_hi - t_lo + 1 : 0;
     rc = set_stash(a, L, stash_a, stash_k, stash_ld, groups, steps);
@@ -748,6 +767,28 @@ int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_la
     rc = dispatch_rev(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
     if (rc) return fail(rc, "forward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
+}
+
+int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                                   const double* var_x, const double* var_y, const double* u, const double* y,
+                                   const double* y2, const double* eps_f, const double* x, double cL, double* gy2,
+                                   double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
+                                   double* stash_k, int64_t stash_ld, void* stream)
+{
+    if (p && p->half) return fail(-1, "problem->half is set: use cbfssm_half_forward_pass_bwd_f64");
+    return forward_pass_bwd_impl(p, L, pack_f, var_x, var_y, u, y, y2, eps_f, x, cL, gy2, nullptr, gpart, t_hi, t_lo,
+                                 gx_carry, stash_a, stash_k, stash_ld, stream);
+}
+
+int cbfssm_half_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
+                                     const double* var_x, const double* var_y, const double* u, const double* y,
+                                     const double* eps_f, const double* x, double cL, double* gx0, double* gpart,
+                                     int t_hi, int t_lo, double* gx_carry, double* stash_a, double* stash_k,
+                                     int64_t stash_ld, void* stream)
+{
+    if (!p || !p->half) return fail(-1, "problem->half must be 1");
+    return forward_pass_bwd_impl(p, L, pack_f, var_x, var_y, u, y, nullptr, eps_f, x, cL, nullptr, gx0, gpart, t_hi,
+                                 t_lo, gx_carry, stash_a, stash_k, stash_ld, stream);
 }
 
 int cbfssm_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,

@@ -98,6 +98,8 @@ struct PassArgs {
     double* part_out;      // one partial per workgroup
     int nseg0;             // bwd: number of segment slots of run 0 (blockIdx.y < nseg0 -> run 0)
     double* dbg;           // diagnostic builds: [workgroup][32] stamp sums (null otherwise)
+    int half;              // CBFSSMHALF forward pass (cbfssmhalf.py:117-172): x_0 from x0, Kalman update on d < dim_y only
+    const double* x0;      // half: (B, dim_x) recognition-model output
 };
 
 struct PredictArgs {
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         act[qi] = (tk < NTASK) && (d < Do);
         const int dc = act[qi] ? d : 0;
         vx[qi] = a.var_x[dc];
-        vy[qi] = (MODE == MODE_FWD) ? a.var_y[dc] : 0.0;
+        vy[qi] = (MODE == MODE_FWD) ? a.var_y[(a.half && dc >= a.dim_y) ? 0 : dc] : 0.0;   // half: var_y has dim_y entries
         il[qi] = a.pk.invl[dc];
         lin[qi] = 0.0;
         lp[qi].init();
@@ -557,9 +559,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         if (act[qi]) {
             double v;
             if (MODE == MODE_FWD) {
-                // x_0 = y_tilde[:, 0] = [y_0, y2_0]                       (cbfssm.py:97,168)
-                v = (d < a.dim_y) ? a.y[(int64_t(bqv[qi]) * T) * a.dim_y + d]
-                                  : a.y2_in[int64_t(c) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
+                // x_0 = y_tilde[:, 0] = [y_0, y2_0]  (cbfssm.py:97,168); half: recognition model (cbfssmhalf.py:106)
+                if (a.half) v = a.x0[int64_t(bqv[qi]) * a.dim_x + d];
+                else v = (d < a.dim_y) ? a.y[(int64_t(bqv[qi]) * T) * a.dim_y + d]
+                                       : a.y2_in[int64_t(c) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
                 if (cval[qi]) a.x_out[int64_t(c) * a.dim_x + d] = v;
             } else {
                 v = resample0 ? a.hid[(int64_t(run) * T + t_first) * N + c] : 0.0;   // cbfssm.py:106,133-136
@@ -597,8 +600,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
             if (MODE == MODE_FWD) {
                 eps_t[qi] = a.eps[int64_t(t) * N + c];                                       // cbfssm.py:209
                 if (act[qi]) {
-                    ytil[qi] = (d < a.dim_y) ? a.y[(int64_t(bqv[qi]) * T + (t + 1)) * a.dim_y + d]    // cbfssm.py:196
-                                             : a.y2_in[(int64_t(t + 1) * N + c) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
+                    if (d < a.dim_y) ytil[qi] = a.y[(int64_t(bqv[qi]) * T + (t + 1)) * a.dim_y + d];      // cbfssm.py:196
+                    else if (!a.half) ytil[qi] = a.y2_in[(int64_t(t + 1) * N + c) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
                 }
             } else {
                 eps_t[qi] = a.eps[(int64_t(run) * T + t) * N + c];                           // cbfssm.py:149
@@ -644,7 +647,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                         const double mu = fmean + kk * ydiff;                          // :218
                         const double omk = 1.0 - kk;
                         const double sig = omk * omk * fvar + kk * kk * vyt;           // :219-220
-                        const bool do_cond = a.condition || (t < R - 1);               // :227
+                        // half: the hidden dims (d >= dim_y) get no Kalman update: k = 0, mu = fmean, sig = fvar, KL = 0
+                        const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);     // :227
                         outv = do_cond ? (mu + eps_t[qi] * sqrt(sig)) : (fmean + eps_t[qi] * sqrt(fvar));   // :221-229
                         if (do_cond && cval[qi]) {
                             // kl_reg = log fvar - log sig + (sig + (mu - fmean)^2)/fvar - 1        (:232)

@@ -67,7 +67,7 @@ typedef struct {
     int32_t M;                  /* inducing points                                                           */
     int32_t recog_len;          /* config['recog_len']      cbfssm.py:120,190                                */
     int32_t condition;          /* feed of model.condition  cbfssm.py:227                                    */
-    int32_t pad_;
+    int32_t half;               /* 1: CBFSSMHALF forward pass (cbfssmhalf.py:117-172), 0: CBFSSM                  */
     double k_factor;            /* config['k_factor']       cbfssm.py:191,214                                */
 } cbfssm_problem;
 
@@ -134,6 +134,21 @@ int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p);
 int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
                             const double* y2, const double* eps_f, double* x, double* kl_part, void* stream);
+
+/*
+ * CBFSSMHALF (cbfssm/model/cbfssmhalf.py:97-172): the forward pass with x_0 = recognition-model output x0 (B,dim_x),
+ * Kalman update on the first dim_y state dims only (var_y has dim_y entries), no backward runs.  problem->half must be 1.
+ * The adjoint also returns gx0 (N,dim_x) = d loss / d x_0 per particle chain (sum over the S particles of a sequence is
+ * the gradient of the recognition output).  t range / stash arguments as in cbfssm_forward_pass_bwd_ex_f64.
+ */
+int cbfssm_half_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
+                                 const double* var_x, const double* var_y, const double* u, const double* y,
+                                 const double* x0, const double* eps_f, double* x, double* kl_part, void* stream);
+int cbfssm_half_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
+                                     const double* var_x, const double* var_y, const double* u, const double* y,
+                                     const double* eps_f, const double* x, double cL, double* gx0, double* gpart,
+                                     int t_hi, int t_lo, double* gx_carry, double* stash_a, double* stash_k,
+                                     int64_t stash_ld, void* stream);
 
 /*
  * Log-likelihood and predictive moments, CBFSSM._build_loss (cbfssm.py:245-251) and _build_prediction

@@ -283,3 +283,89 @@ class CBFSSMOracle:
 
 def elbo_step(config, params, u, y, noise, condition=True, trace=None):
     return CBFSSMOracle(config, params).run(u, y, noise, condition, trace)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cbfssm/model/cbfssmhalf.py  (forward-only variant: recognition model for x_0, Kalman update on the observed dims)
+# ---------------------------------------------------------------------------------------------------------------------
+def gru_recognition(recog, u, y, recog_len):
+    """cbfssmhalf.py:64-95, recog == 'rnn': TF-1.8 GRUCell(16) over the reversed first recog_len steps of [u, y],
+    then a dense layer to dim_x.  recog: dict gate_kernel (in+16, 32), gate_bias (32), cand_kernel (in+16, 16),
+    cand_bias (16), dense_kernel (16, dim_x), dense_bias (dim_x)."""
+    uy = np.concatenate((u, y), axis=2)[:, :recog_len, :][:, ::-1, :]             # :77-78,83
+    h = np.zeros((u.shape[0], recog['cand_bias'].shape[0]))                       # :80
+
+    def sigmoid(v):
+        return 1.0 / (1.0 + np.exp(-v))
+    for t in range(uy.shape[1]):
+        x = uy[:, t, :]
+        gates = sigmoid(np.concatenate((x, h), 1) @ recog['gate_kernel'] + recog['gate_bias'])
+        r, z = np.split(gates, 2, axis=1)
+        c = np.tanh(np.concatenate((x, r * h), 1) @ recog['cand_kernel'] + recog['cand_bias'])
+        h = z * h + (1.0 - z) * c
+    return h @ recog['dense_kernel'] + recog['dense_bias']                        # :86
+
+
+class CBFSSMHALFOracle:
+    """cbfssm/model/cbfssmhalf.py:7-211 as a function of explicit (params, u, y, eps_f, condition)."""
+
+    def __init__(self, config, params):
+        self.config = config
+        self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
+        p = params
+        self.gp_f = GPModel(p['f.zeta_pos'], p['f.zeta_mean'], p['f.zeta_var_unc'],
+                            p['f.variance_unc'], p['f.lengthscales_unc'])          # :24-33
+        self.var_x = tf_forward(p['var_x_unc'])                                      # :36-37
+        self.var_y = tf_forward(p['var_y_unc'])                                      # :38-39  (dim_y entries)
+        self.params = params
+
+    def recog(self, u, y):
+        kind = self.config.get('recog_model', 'rnn')                                 # :71-74
+        if kind == 'output':                                                         # :76-80
+            x0 = np.concatenate((y[:, 0, :], np.zeros((y.shape[0], self.dim_x - self.dim_y))), axis=1)
+        else:
+            x0 = gru_recognition({k[6:]: v for k, v in self.params.items() if k.startswith('recog.')}, u, y,
+                                 self.config['recog_len'])
+        return x0
+
+    def run(self, u, y, noise, condition=True):
+        u, y = np.asarray(u, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        B, T, _ = u.shape
+        S, R, kf = self.config['samples'], self.config['recog_len'], self.config['k_factor']
+        dim_x, dim_y = self.dim_x, self.dim_y
+        x = np.zeros((T, B, S, dim_x))
+        x[0] = np.tile(self.recog(u, y)[:, None, :], (1, S, 1))                      # :80,87,106-107
+        prob = np.zeros((T - 1,))
+        for t in range(T - 1):
+            u_t = np.tile(u[:, t, None, :], (1, S, 1))
+            y_t = np.tile(y[:, t + 1, None, :], (1, S, 1))                           # :133
+            in_t = np.concatenate((x[t], u_t), axis=2)
+            fmean, fvar = self.gp_f.predict(in_t.reshape(B * S, self.dim_u + dim_x))
+            fmean = fmean.reshape(B, S, dim_x) + in_t[:, :, :dim_x]                  # :140-142
+            fvar = fvar.reshape(B, S, dim_x) + self.var_x                            # :143
+            eps = np.tile(noise['eps_f'][t][:, :, None], (1, 1, dim_x))              # :146
+            var_y_t = np.tile(self.var_y[None, None, :], (B, S, 1)) + (kf - 1.) * fvar[:, :, :dim_y]   # :149-151
+            y_diff = y_t - fmean[:, :, :dim_y]                                       # :152
+            s = var_y_t + fvar[:, :, :dim_y]                                         # :153
+            k = fvar[:, :, :dim_y] * (1.0 / s)                                       # :154
+            pad = np.zeros((B, S, dim_x - dim_y))
+            mu = fmean + np.concatenate((k * y_diff, pad), axis=2)                   # :156
+            sig = np.square(np.ones((B, S, dim_x)) - np.concatenate((k, pad), axis=2)) * fvar   # :157-158
+            sig = sig + np.concatenate((np.square(k) * var_y_t, pad), axis=2)        # :159
+            x_cond = mu + eps * np.sqrt(sig)                                         # :160
+            x_nocond = fmean + eps * np.sqrt(fvar)                                   # :163
+            do_cond = bool(condition) or (t < R - 1)                                 # :166
+            x[t + 1] = x_cond if do_cond else x_nocond
+            kl_reg = np.log(fvar) - np.log(sig) + (sig + np.power(mu - fmean, 2.)) / fvar - 1.   # :171
+            prob[t] = np.sum(kl_reg) * (0.5 if do_cond else 0.0)
+        x_final = np.transpose(x, (1, 0, 2, 3))
+        y_final = x_final[..., :dim_y]
+        kl_x = np.sum(prob)
+        var = self.var_y[:dim_y]
+        log_probs = -0.5 * np.sum(np.square(y[:, :, None, :] - y_final) / var + np.log(2 * np.pi) + np.log(var), axis=-1)
+        loglik = np.sum(log_probs)                                                   # :181-189
+        kl_z_f = self.gp_f.prior_kl()                                                # :192
+        lf = self.config['loss_factors']
+        elbo = loglik * lf[0] / S - kl_x * lf[0] / S - kl_z_f                        # :195-198
+        return {'loss': -elbo, 'loglik': loglik, 'kl_x': kl_x, 'kl_z_f': kl_z_f, 'x_final': x_final,
+                'pred_mean': np.mean(y_final, axis=2), 'pred_var': np.var(y_final, axis=2) + var}

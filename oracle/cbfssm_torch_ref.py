@@ -13,6 +13,7 @@ cannot give:
 Every block cites the reference file:line it restates (paths relative to /root/reference).
 """
 import math
+import numpy as np
 import torch
 
 JITTER = 1e-8
@@ -180,3 +181,74 @@ def loss_and_grads(config, params_np, u_np, y_np, noise_np, condition=True):
     out['loss'].backward()
     grads = {k: v.grad.detach().numpy().copy() for k, v in params.items()}
     return {k: float(v.detach()) for k, v in out.items()}, grads
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cbfssm/model/cbfssmhalf.py
+# ---------------------------------------------------------------------------------------------------------------------
+def gru_recognition(recog, u, y, recog_len):
+    """cbfssmhalf.py:82-93: TF-1.8 GRUCell(16) on the reversed first recog_len steps of [u, y] + dense to dim_x."""
+    uy = torch.flip(torch.cat((u, y), dim=2)[:, :recog_len, :], dims=[1])
+    h = torch.zeros(u.shape[0], recog['cand_bias'].shape[0], dtype=u.dtype, device=u.device)
+    for t in range(uy.shape[1]):
+        x = uy[:, t, :]
+        gates = torch.sigmoid(torch.cat((x, h), 1) @ recog['gate_kernel'] + recog['gate_bias'])
+        r, z = torch.chunk(gates, 2, dim=1)
+        c = torch.tanh(torch.cat((x, r * h), 1) @ recog['cand_kernel'] + recog['cand_bias'])
+        h = z * h + (1.0 - z) * c
+    return h @ recog['dense_kernel'] + recog['dense_bias']
+
+
+def half_elbo_step(config, params, u, y, noise, condition=True):
+    """cbfssm/model/cbfssmhalf.py:20-199 on float64 CPU tensors (params may require grad)."""
+    dim_u, dim_y, dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
+    S, R, kf = config['samples'], config['recog_len'], config['k_factor']
+    lf = config['loss_factors']
+    B, T, _ = u.shape
+    p = params
+    gp_f = GPModel(p['f.zeta_pos'], p['f.zeta_mean'], p['f.zeta_var_unc'], p['f.variance_unc'], p['f.lengthscales_unc'])
+    var_x, var_y = tf_forward(p['var_x_unc']), tf_forward(p['var_y_unc'])
+    if config.get('recog_model', 'rnn') == 'output':
+        x0 = torch.cat((y[:, 0, :], torch.zeros(B, dim_x - dim_y, dtype=u.dtype)), dim=1)
+    else:
+        x0 = gru_recognition({k[6:]: v for k, v in p.items() if k.startswith('recog.')}, u, y, R)
+    xs = [x0[:, None, :].repeat(1, S, 1)]
+    probf = []
+    for t in range(T - 1):
+        u_t = u[:, t, None, :].repeat(1, S, 1)
+        y_t = y[:, t + 1, None, :].repeat(1, S, 1)
+        in_t = torch.cat((xs[t], u_t), dim=2)
+        fmean, fvar = gp_f.predict(in_t.reshape(B * S, dim_u + dim_x))
+        fmean = fmean.reshape(B, S, dim_x) + in_t[:, :, :dim_x]
+        fvar = fvar.reshape(B, S, dim_x) + var_x
+        eps = noise['eps_f'][t][:, :, None].repeat(1, 1, dim_x)
+        var_y_t = var_y[None, None, :].repeat(B, S, 1) + (kf - 1.) * fvar[:, :, :dim_y]
+        y_diff = y_t - fmean[:, :, :dim_y]
+        s = var_y_t + fvar[:, :, :dim_y]
+        k = fvar[:, :, :dim_y] * torch.reciprocal(s)
+        pad = torch.zeros(B, S, dim_x - dim_y, dtype=u.dtype)
+        mu = fmean + torch.cat((k * y_diff, pad), dim=2)
+        sig = torch.square(1.0 - torch.cat((k, pad), dim=2)) * fvar + torch.cat((torch.square(k) * var_y_t, pad), dim=2)
+        x_cond = mu + eps * torch.sqrt(sig)
+        x_nocond = fmean + eps * torch.sqrt(fvar)
+        do_cond = bool(condition) or (t < R - 1)
+        xs.append(x_cond if do_cond else x_nocond)
+        kl_reg = torch.log(fvar) - torch.log(sig) + (sig + torch.pow(mu - fmean, 2.)) / fvar - 1.
+        probf.append(torch.sum(kl_reg) * (0.5 if do_cond else 0.0))
+    x_final = torch.stack(xs).permute(1, 0, 2, 3)
+    y_final = x_final[..., :dim_y]
+    kl_x = torch.sum(torch.stack(probf)) if probf else torch.zeros((), dtype=u.dtype)
+    var = var_y[:dim_y]
+    loglik = torch.sum(torch.distributions.Normal(y_final, torch.sqrt(var)).log_prob(y[:, :, None, :]))
+    kl_z_f = gp_f.prior_kl()
+    elbo = loglik * float(lf[0]) / S - kl_x * float(lf[0]) / S - kl_z_f
+    return {'loss': -elbo, 'loglik': loglik, 'kl_x': kl_x, 'kl_z_f': kl_z_f, 'x_final': x_final}
+
+
+def half_loss_and_grads(config, params_np, u_np, y_np, noise_np, condition=True):
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params_np.items()}
+    noise = {k: torch.tensor(v, dtype=torch.float64) for k, v in noise_np.items()}
+    out = half_elbo_step(config, params, torch.tensor(u_np), torch.tensor(y_np), noise, condition)
+    out['loss'].backward()
+    return float(out['loss'].detach()), {k: (v.grad.detach().numpy().copy() if v.grad is not None else np.zeros(v.shape))
+                                for k, v in params.items()}

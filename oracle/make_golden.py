@@ -59,5 +59,27 @@ def main():
         print(name, os.path.getsize(path) // 1024, 'KiB', 'loss', blob['c1_loss'])
 
 
+def main_half():
+    """CBFSSMHALF fixture (cbfssm/model/cbfssmhalf.py): GRU recognition model, both `condition` settings."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_oracle import _half_setup
+    w, cfg, p, u, y, noise = _half_setup('rnn', T=13, B=3, S=5, M=14, recog_len=4)
+    blob = {'workload_' + k: np.asarray(v) for k, v in syn.workload_dict(w).items() if k != 'name'}
+    blob.update({'param_' + k: v for k, v in p.items()})
+    blob.update({'u': u, 'y': y, 'noise_eps_f': noise['eps_f'], 'var_y_cfg': cfg['var_y']})
+    for cond in (True, False):
+        tag = 'c1_' if cond else 'c0_'
+        res = orc.CBFSSMHALFOracle(cfg, p).run(u, y, noise, cond)
+        for k in ('loss', 'loglik', 'kl_x', 'kl_z_f', 'pred_mean', 'pred_var', 'x_final'):
+            blob[tag + k] = np.asarray(res[k])
+        loss, grads = tref.half_loss_and_grads(cfg, p, u, y, noise, cond)
+        assert abs(loss - res['loss']) <= 1e-9 * abs(res['loss'])
+        blob.update({tag + 'grad_' + k: g for k, g in grads.items()})
+    path = os.path.join(ROOT, 'tests', 'golden', 'half_tiny.npz')
+    np.savez_compressed(path, **blob)
+    print('half_tiny', os.path.getsize(path) // 1024, 'KiB', 'loss', blob['c1_loss'])
+
+
 if __name__ == '__main__':
     main()
+    main_half()

@@ -6,7 +6,7 @@ import pytest
 from cbfssm.model.base_model import shuffle_order, BaseModel
 from cbfssm.model.session import OutOfRangeError
 from cbfssm.datasets import BaseDS, make_synthetic_ds, Sarcos, Actuator, RoboMove
-from cbfssm.model import CBFSSM, CBFSSMHALF
+from cbfssm.model import CBFSSM, CBFSSMHALF, PRSSM
 from cbfssm import synthetic as syn
 
 
@@ -98,7 +98,12 @@ def test_model_surface_without_gpu():
     assert np.all(np.abs(iv['f.zeta_pos']) <= cfg['zeta_pos'])
     np.testing.assert_allclose(np.logaddexp(0, iv['var_x_unc']) + 1e-10, cfg['var_x'], rtol=1e-9)
     with pytest.raises(NotImplementedError):
-        CBFSSMHALF(cfg)
+        PRSSM(cfg)
+    hcfg = dict(cfg)
+    hcfg['var_y'] = np.asarray([0.3 ** 2] * w.dim_y)
+    h = CBFSSMHALF(hcfg)
+    assert h._init_values['recog.gate_kernel'].shape == (w.dim_u + w.dim_y + 16, 32)
+    assert 'IP pos b' not in h.var_dict and 'IP pos f' in h.var_dict
     with m.graph.as_default():
         pass
     bad = dict(cfg)

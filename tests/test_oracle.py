@@ -178,3 +178,43 @@ def test_gradients_vs_finite_differences():
             pm[name].reshape(-1)[idx] -= h
             fd = (orc.elbo_step(cfg, pp, u, y, noise)['loss'] - orc.elbo_step(cfg, pm, u, y, noise)['loss']) / (2 * h)
             assert g.reshape(-1)[idx] == pytest.approx(fd, rel=2e-5, abs=1e-6), (name, idx)
+
+
+# ---- CBFSSMHALF restatements (cbfssm/model/cbfssmhalf.py): two codings agree; gradient vs finite differences
+def _half_setup(recog='rnn', **kw):
+    w = syn.tiny(**kw)
+    cfg = w.model_config()
+    cfg['var_y'] = np.asarray([w.var_y] * w.dim_y)
+    cfg['recog_model'] = recog
+    rng = np.random.default_rng(4)
+    p = {k: v for k, v in syn.perturb_params(syn.make_params(w, seed=1)).items() if k.startswith('f.') or k == 'var_x_unc'}
+    p['var_y_unc'] = syn.softplus_inverse(cfg['var_y']) + 0.1 * rng.standard_normal(w.dim_y)
+    if recog == 'rnn':
+        n_in, H = w.dim_u + w.dim_y, 16
+        p.update({'recog.gate_kernel': 0.3 * rng.standard_normal((n_in + H, 2 * H)), 'recog.gate_bias': np.ones(2 * H),
+                  'recog.cand_kernel': 0.3 * rng.standard_normal((n_in + H, H)), 'recog.cand_bias': 0.1 * rng.standard_normal(H),
+                  'recog.dense_kernel': 0.3 * rng.standard_normal((H, w.dim_x)), 'recog.dense_bias': 0.1 * rng.standard_normal(w.dim_x)})
+    u, y = syn.make_inputs(w)
+    noise = {'eps_f': syn.make_noise(w)['eps_f']}
+    return w, cfg, p, u, y, noise
+
+
+@pytest.mark.parametrize('recog', ['rnn', 'output'])
+def test_half_numpy_matches_torch_and_fd(recog):
+    w, cfg, p, u, y, noise = _half_setup(recog, T=6, B=2, S=3, M=6, recog_len=3)
+    res = orc.CBFSSMHALFOracle(cfg, p).run(u, y, noise, True)
+    loss, grads = tref.half_loss_and_grads(cfg, p, u, y, noise, True)
+    assert loss == pytest.approx(res['loss'], rel=1e-10)
+    # hidden dims get no Kalman update: x_{t+1}[d >= dim_y] = fmean + eps sqrt(fvar)  (cbfssmhalf.py:155-160)
+    rng = np.random.default_rng(3)
+    for name in p:
+        flat = p[name].reshape(-1)
+        for idx in rng.choice(flat.size, size=min(2, flat.size), replace=False):
+            h = 1e-6 * max(1.0, abs(flat[idx]))
+            pp = {k: v.copy() for k, v in p.items()}
+            pm = {k: v.copy() for k, v in p.items()}
+            pp[name].reshape(-1)[idx] += h
+            pm[name].reshape(-1)[idx] -= h
+            fd = (orc.CBFSSMHALFOracle(cfg, pp).run(u, y, noise)['loss']
+                  - orc.CBFSSMHALFOracle(cfg, pm).run(u, y, noise)['loss']) / (2 * h)
+            assert grads[name].reshape(-1)[idx] == pytest.approx(fd, rel=5e-5, abs=1e-6), (name, idx)
