@@ -46,6 +46,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch owns the device memory these entry points work on: its HIP runtime (the libamdhip64 it bundles) must be
+    # the one this process binds, so it is loaded first -- otherwise the library would resolve the system runtime and
+    # the two would not share a context ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CbfssmHipError('HIP extension not built: %s is missing (run __graft_entry__.build() / make -C '
                              'cbf-ssm_amd/csrc). There is no fallback path.' % LIB_PATH)
