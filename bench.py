@@ -124,15 +124,16 @@ def main():
         def step():
             return stepper.step(u, y, draw_noise(), condition=True)
     else:
-        eng = ops.HipElbo(cfg, dev)
+        from cbfssm.hip.train import HipElboGrad
+        eng = HipElboGrad(cfg, dev, dist if world > 1 else None, require_adjoint=False)
+        out8 = torch.zeros(8, dtype=torch.float64, device=dev)
 
         def step():
-            eng.prepare(params)
-            ws = eng.run(u, y, draw_noise(), condition=True)
-            if world > 1:
-                red.copy_(ws.out)
-                dist.all_reduce(red)       # data terms of the ELBO summed over ranks (RCCL over xGMI)
-            return ws.out
+            # what Trainer's test pass fetches (loss only); N>1: the three data terms are all-reduced inside
+            loss_t, _, ws = eng.forward(params, u, y, draw_noise(), condition=True)
+            out8.copy_(ws.out)
+            out8[6] = loss_t
+            return out8
 
     def sync():
         if world > 1:

@@ -31,7 +31,7 @@ class PackLayout(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('B', 'S', 'T', 'dim_x', 'dim_u', 'dim_y', 'M', 'recog_len', 'condition',
-                                          'half')] + [('k_factor', C.c_double)]
+                                          'half', 'group0', 'ngroups')] + [('k_factor', C.c_double)]
 
 
 class CbfssmHipError(RuntimeError):
@@ -105,4 +105,5 @@ def make_problem(B, S, T, dim_x, dim_u, dim_y, M, recog_len, k_factor, condition
     p = Problem()
     p.B, p.S, p.T, p.dim_x, p.dim_u, p.dim_y, p.M = int(B), int(S), int(T), int(dim_x), int(dim_u), int(dim_y), int(M)
     p.recog_len, p.condition, p.half, p.k_factor = int(recog_len), int(bool(condition)), int(bool(half)), float(k_factor)
+    p.group0, p.ngroups = 0, 0
     return p

@@ -12,6 +12,7 @@ equals a single-device evaluation of the global batch (cbfssm.py:257-261 sums ov
 """
 import ctypes as C
 import math
+import os
 import torch
 
 from . import lib as _l
@@ -92,8 +93,7 @@ class HipElboGrad:
             self._ws[key] = ops.ElboWorkspace(prob, dev, keep_h=False)
         ws = self._ws[key]
         hid_b, eps_b, eps_f = (_f64(noise[k], dev) for k in ('hid_b', 'eps_b', 'eps_f'))
-        ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f,
-                         cfg['loss_factors'], ws)
+        self._elbo_forward(prob, ws, c, u, y, hid_b, eps_b, eps_f)
         out = ws.out
         if self.dist is not None:
             # data terms summed over the ranks' shards, prior KL counted once (cbfssm.py:257-261)
@@ -147,7 +147,7 @@ class HipElboGrad:
         self.last_ws = ws
         hid_b, eps_b, eps_f = (_f64(noise[k], dev) for k in ('hid_b', 'eps_b', 'eps_f'))
         lf = cfg['loss_factors']
-        ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws)
+        self._elbo_forward(prob, ws, c, u, y, hid_b, eps_b, eps_f)
 
         # ---- adjoint time loops
         st = _stream()
@@ -156,7 +156,12 @@ class HipElboGrad:
         red = self.red
         sf, sb = self.slab_f, self.slab_b
         gB_f = gB_b = None
-        if not self.stash:
+        split = self._split(prob)
+        if not self.stash and split is not None:
+            self._adjoint_split(prob, split, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE)
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
+        elif not self.stash:
             rc = lib.cbfssm_forward_pass_bwd_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
                                                  _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
                                                  _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), cL,
@@ -210,6 +215,105 @@ class HipElboGrad:
         terms = {'loglik': loglik, 'kl_x': kl_x, 'entropy': entropy, 'kl_z_f': kl_z_f, 'kl_z_b': kl_z_b,
                  'info': ws.out[7]}
         return -elbo, grads, terms
+
+    # ---- chain-group split: chains never interact, so a pass can be issued in two pieces on two HIP streams.  When the
+    # number of 16-chain groups is not a multiple of the CU count (C3: 320 groups on 256 CUs), the one-workgroup-per-
+    # group forward-direction kernels would leave 3/4 of the chip idle in their last round; the remainder groups are
+    # run early and the many-workgroup backward-run kernels of the other piece fill the idle CUs meanwhile.
+    def _split(self, prob):
+        if self.stash or os.environ.get('CBFSSM_NO_SPLIT'):
+            return None
+        groups = (prob.B * prob.S + 15) // 16
+        force = os.environ.get('CBFSSM_SPLIT_MAIN')            # tests: force a split at this group index
+        if force:
+            return (int(force), groups - int(force)) if 0 < int(force) < groups else None
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if groups <= ncu or groups % ncu == 0:
+            return None
+        main = (groups // ncu) * ncu
+        return main, groups - main
+
+    def _sub_problem(self, prob, g0, ng):
+        q = _l.Problem()
+        C.memmove(C.byref(q), C.byref(prob), C.sizeof(_l.Problem))
+        q.group0, q.ngroups = int(g0), int(ng)
+        return q
+
+    def _side_stream(self):
+        if getattr(self, '_s1', None) is None:
+            self._s1 = torch.cuda.Stream(device=self.device)
+        return self._s1
+
+    def _elbo_forward(self, prob, ws, c, u, y, hid_b, eps_b, eps_f):
+        lf = self.config['loss_factors']
+        split = self._split(prob)
+        if split is None:
+            ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws)
+            return
+        lib = _l.load()
+        main, rest = split
+        p_main, p_rest = self._sub_problem(prob, 0, main), self._sub_problem(prob, main, rest)
+        s0, s1 = torch.cuda.current_stream(), self._side_stream()
+        st0, st1 = C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)
+        lb, lf_ = C.byref(self.pack_b.layout), C.byref(self.pack_f.layout)
+        e_eps = _ptr(eps_f) if eps_f.numel() else None
+
+        def bwd(q, st):
+            _l.check(lib.cbfssm_backward_pass_f64(C.byref(q), lb, _ptr(self.pack_b.buf), _ptr(c['var_x']), _ptr(u), _ptr(y),
+                                                  _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all),
+                                                  _ptr(ws.ent_part), st), 'cbfssm_backward_pass_f64')
+
+        def fwd(q, st):
+            _l.check(lib.cbfssm_forward_pass_f64(C.byref(q), lf_, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
+                                                 _ptr(u), _ptr(y), _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.kl_part),
+                                                 st), 'cbfssm_forward_pass_f64')
+        e0 = torch.cuda.Event()
+        e0.record(s0)
+        bwd(p_rest, st0)                       # the remainder groups first ...
+        fwd(p_rest, st0)                       # ... their (few, long) forward workgroups overlap
+        s1.wait_event(e0)
+        bwd(p_main, st1)                       # ... the many short backward-run workgroups of the main piece
+        e1 = torch.cuda.Event()
+        e1.record(s1)
+        s0.wait_event(e1)
+        fwd(p_main, st0)
+        pb = C.byref(prob)
+        rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(c['var_y']), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part),
+                                           _ptr(ws.pred_mean), _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st0)
+        _l.check(rc, 'cbfssm_loglik_moments_f64')
+        rc = lib.cbfssm_elbo_combine_f64(pb, float(lf[0]), float(lf[1]), _ptr(ws.ll_part), ws.ll_part.numel(),
+                                         _ptr(ws.kl_part), ws.kl_part.numel(), _ptr(ws.ent_part), ws.ent_part.numel(),
+                                         _ptr(self.pack_f.scal), _ptr(self.pack_b.scal), _ptr(ws.out), st0)
+        _l.check(rc, 'cbfssm_elbo_combine_f64')
+
+    def _adjoint_split(self, prob, split, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE):
+        lib = _l.load()
+        main, rest = split
+        p_main, p_rest = self._sub_problem(prob, 0, main), self._sub_problem(prob, main, rest)
+        s0, s1 = torch.cuda.current_stream(), self._side_stream()
+        st0, st1 = C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)
+        lb, lf_ = C.byref(self.pack_b.layout), C.byref(self.pack_f.layout)
+        e_eps = _ptr(eps_f) if eps_f.numel() else None
+
+        def rfwd(q, st):
+            _l.check(lib.cbfssm_forward_pass_bwd_f64(C.byref(q), lf_, _ptr(self.pack_f.buf), _ptr(c['var_x']),
+                                                     _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2), e_eps, _ptr(ws.x),
+                                                     cL, _ptr(ws.gy2), _ptr(ws.gpart_f), st), 'cbfssm_forward_pass_bwd_f64')
+
+        def rbwd(q, st):
+            _l.check(lib.cbfssm_backward_pass_bwd_f64(C.byref(q), lb, _ptr(self.pack_b.buf), _ptr(c['var_x']), _ptr(u),
+                                                      _ptr(y), _ptr(hid_b), _ptr(eps_b), _ptr(ws.h_all), _ptr(ws.gy2),
+                                                      cE, _ptr(ws.gpart_b), st), 'cbfssm_backward_pass_bwd_f64')
+        rfwd(p_main, st0)                      # a whole number of rounds over the CUs
+        e2 = torch.cuda.Event()
+        e2.record(s0)
+        rfwd(p_rest, st0)                      # few long workgroups ...
+        s1.wait_event(e2)
+        rbwd(p_main, st1)                      # ... next to the main piece's backward-run adjoint
+        e3 = torch.cuda.Event()
+        e3.record(s1)
+        rbwd(p_rest, st0)
+        s0.wait_event(e3)
 
     def _adjoint_stash(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):
         """Stash-mode adjoint (M > 112): time-chunked launches, every launch followed by one float64 GEMM that

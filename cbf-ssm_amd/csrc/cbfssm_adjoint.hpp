@@ -60,6 +60,7 @@ struct RevArgs {
     int chunk_steps;
     int half;              // CBFSSMHALF forward pass
     double* gx0;           // half: (N, dim_x) d loss / d x_0 per chain (summed over the particles by the caller)
+    int group0, gtotal;    // this launch covers chain groups [group0, group0 + gridDim.x) of gtotal
 };
 
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
@@ -104,14 +105,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
     const int naux = D - Do;
     const int dob = a.dim_x - a.dim_y;
-    const int c0 = blockIdx.x * 16;
+    const int gx = blockIdx.x + a.group0;               // chain group of this workgroup
+    const int c0 = gx * 16;
     const int c = min(c0 + nl, N - 1);
     const bool cvalid = (c0 + nl) < N;
     const int bq = c / S;
     const int run = (MODE == MODE_BWD) ? int(blockIdx.y) : 0;
     const int R = a.recog_len, P = 2 * R;
     const int KSr = a.KSr;                              // k-steps of K^-1 that carry data: ceil(M/4)
-    const int64_t wg_linear = (int64_t(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int64_t wg_linear = (int64_t(blockIdx.z) * gridDim.y + blockIdx.y) * a.gtotal + gx;
 
     // ---- loop-invariant operands (Z~ rows and cz of the owned row blocks stay in VGPRs; the small operand images
     // muA/s2A/muB/s2B/ZT are re-read from L1/L2 where they are used: the VGPRs hold the adjoint accumulators)

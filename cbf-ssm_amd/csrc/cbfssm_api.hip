@@ -434,6 +434,7 @@ static int check_problem(const cbfssm_problem* p, const cbfssm_pack_layout* L, i
 static int pass_nc(const cbfssm_problem* p, int mode)
 {
     if (p->M > 112) return 1;     // two column blocks of the larger tiles do not fit the LDS
+    if (p->ngroups > 0) return 1; // chain-group split is in units of 16 chains
     const int64_t n = int64_t(p->B) * p->S;
     const char* e = getenv(mode == MODE_FWD ? "CBFSSM_NC_FWD" : "CBFSSM_NC_BWD");
     if (e && !p->half) return atoi(e) == 2 ? 2 : 1;
@@ -441,6 +442,19 @@ static int pass_nc(const cbfssm_problem* p, int mode)
     // on the forward pass (320 -> 160 workgroups)
     if (mode == MODE_BWD) return n >= 32 * 128 ? 2 : 1;
     return 1;   // (also required by half mode: only the one-group kernel knows x0)
+}
+
+// chain-group range of a call: (first group, number of groups, total) in units of 16*nc chains
+static int group_range(const cbfssm_problem* p, int nc, int* g0, int* ng, int* gt)
+{
+    const int64_t n = int64_t(p->B) * p->S;
+    const int total16 = int((n + 15) / 16);
+    *gt = int((n + 16 * nc - 1) / (16 * nc));
+    if (p->ngroups <= 0) { *g0 = 0; *ng = *gt; return 0; }
+    if (p->group0 < 0 || p->group0 + p->ngroups > total16) return fail(-1, "bad chain-group range [%d, +%d) of %d", p->group0, p->ngroups, total16);
+    if (nc != 1) return fail(-1, "internal: chain-group split needs the one-group kernels");
+    *g0 = p->group0; *ng = p->ngroups;
+    return 0;
 }
 
 static void bwd_segments(const cbfssm_problem* p, int* nseg0, int* nseg1)
@@ -572,8 +586,7 @@ int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p)
     if (!p || p->recog_len < 1) return -1;
     int n0, n1;
     bwd_segments(p, &n0, &n1);
-    const int nc = pass_nc(p, MODE_BWD);
-    const int64_t groups = (int64_t(p->B) * p->S + 16 * nc - 1) / (16 * nc);
+    const int64_t groups = (int64_t(p->B) * p->S + 15) / 16;     // upper bound over both tilings (1 or 2 groups per WG)
     return groups * (n0 + n1);
 }
 
@@ -598,7 +611,11 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
     bwd_segments(p, &n0, &n1);
     a.nseg0 = n0;
     const int nc = pass_nc(p, MODE_BWD);
-    dim3 grid(unsigned((a.N + 16 * nc - 1) / (16 * nc)), unsigned(n0 + n1));
+    int g0, ng, gt;
+    rc = group_range(p, nc, &g0, &ng, &gt);
+    if (rc) return rc;
+    a.group0 = g0; a.gtotal = gt;
+    dim3 grid(unsigned(ng), unsigned(n0 + n1));
     rc = dispatch_pass(L->NBLK, L->DK, MODE_BWD, a, grid, nc, (hipStream_t)stream);
     if (rc) return fail(rc, "backward_pass launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
@@ -607,8 +624,7 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
 int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p)
 {
     if (!p) return -1;
-    const int nc = pass_nc(p, MODE_FWD);
-    return (int64_t(p->B) * p->S + 16 * nc - 1) / (16 * nc);
+    return (int64_t(p->B) * p->S + 15) / 16;
 }
 
 static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
@@ -632,7 +648,11 @@ static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.dbg = g_dbg;
     a.half = p->half; a.x0 = x0;
     const int nc = pass_nc(p, MODE_FWD);
-    dim3 grid(unsigned((a.N + 16 * nc - 1) / (16 * nc)), 1);
+    int g0, ng, gt;
+    rc = group_range(p, nc, &g0, &ng, &gt);
+    if (rc) return rc;
+    a.group0 = g0; a.gtotal = gt;
+    dim3 grid(unsigned(ng), 1);
     rc = dispatch_pass(L->NBLK, L->DK, MODE_FWD, a, grid, nc, (hipStream_t)stream);
     if (rc) return fail(rc, "forward_pass launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
@@ -763,7 +783,11 @@ static int forward_pass_bwd_impl(const cbfssm_problem* p, const cbfssm_pack_layo
     const int steps = t_hi >= t_lo ? t_hi - t_lo + 1 : 0;
     rc = set_stash(a, L, stash_a, stash_k, stash_ld, groups, steps);
     if (rc) return rc;
-    dim3 grid(unsigned(groups), 1);
+    int g0, ng, gt;
+    rc = group_range(p, 1, &g0, &ng, &gt);
+    if (rc) return rc;
+    a.group0 = g0; a.gtotal = gt;
+    dim3 grid(unsigned(ng), 1);
     rc = dispatch_rev(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
     if (rc) return fail(rc, "forward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
@@ -822,7 +846,11 @@ int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_l
     const int per = (seg1 - seg0 + nchunk - 1) / nchunk;
     rc = set_stash(a, L, stash_a, stash_k, stash_ld, groups * 2 * nchunk, per * 2 * p->recog_len);
     if (rc) return rc;
-    dim3 grid(unsigned(groups), 2, unsigned(nchunk));
+    int g0, ng, gt;
+    rc = group_range(p, 1, &g0, &ng, &gt);
+    if (rc) return rc;
+    a.group0 = g0; a.gtotal = gt;
+    dim3 grid(unsigned(ng), 2, unsigned(nchunk));
     rc = dispatch_rev(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
     if (rc) return fail(rc, "backward_pass_bwd launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;

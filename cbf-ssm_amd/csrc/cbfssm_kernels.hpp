@@ -100,6 +100,7 @@ struct PassArgs {
     double* dbg;           // diagnostic builds: [workgroup][32] stamp sums (null otherwise)
     int half;              // CBFSSMHALF forward pass (cbfssmhalf.py:117-172): x_0 from x0, Kalman update on d < dim_y only
     const double* x0;      // half: (B, dim_x) recognition-model output
+    int group0, gtotal;    // this launch covers workgroup tiles [group0, group0 + gridDim.x) of gtotal (chain-group split)
 };
 
 struct PredictArgs {
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do;
     const int naux = a.D - Do;                       // rows of the GP input that are not chain state
-    const int c0 = blockIdx.x * 16 * NC;
+    const int gx = blockIdx.x + a.group0;            // chain group of this workgroup
+    const int c0 = gx * 16 * NC;
 
     // ---- time range of this workgroup
     int t_first, nsteps, dir, run = 0;
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         const int lo = (k > 1) ? (P * (k - 1) - o) : 0;
         t_first = hi; nsteps = hi - lo + 1; dir = -1;
         if (nsteps <= 0) {
-            if (tid == 0) a.part_out[blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
+            if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = 0.0;
             return;
         }
     }
@@ -697,10 +699,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         }
     }
     const double tot = block_sum(v, red, tid, NT);
-    if (tid == 0) a.part_out[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = tot;
 #ifdef CBF_REV_STAMPS
     if (a.dbg && l == 0 && (w == 0 || w == W - 1)) {
-        double* o = a.dbg + (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * 64 + (w == 0 ? 0 : 32);
+        double* o = a.dbg + (int64_t(blockIdx.y) * a.gtotal + gx) * 64 + (w == 0 ? 0 : 32);
         for (int i = 0; i < 7; ++i) { o[i] = double(st_c[i]); o[7 + i] = double(st_w[i]); }
         for (int i = 0; i < 12; ++i) o[14 + i] = double(st_m[i]);
     }
@@ -733,7 +735,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do;
     const int naux = a.D - Do;
-    const int c0 = blockIdx.x * 32;
+    const int gx = blockIdx.x + a.group0;
+    const int c0 = gx * 32;
 
     int t_first, nsteps, dir, run = 0;
     const int R = a.recog_len, P = 2 * R;
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
         const int lo = (k > 1) ? (P * (k - 1) - o) : 0;
         t_first = hi; nsteps = hi - lo + 1; dir = -1;
         if (nsteps <= 0) {
-            if (tid == 0) a.part_out[blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
+            if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = 0.0;
             return;
         }
     }
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
             }
         }
     const double tot = block_sum(v, red, tid, NT);
-    if (tid == 0) a.part_out[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = tot;
 }
 
 }  // namespace cbfssm

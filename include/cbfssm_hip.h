@@ -68,6 +68,9 @@ typedef struct {
     int32_t recog_len;          /* config['recog_len']      cbfssm.py:120,190                                */
     int32_t condition;          /* feed of model.condition  cbfssm.py:227                                    */
     int32_t half;               /* 1: CBFSSMHALF forward pass (cbfssmhalf.py:117-172), 0: CBFSSM                  */
+    int32_t group0, ngroups;    /* chain-group split: this call handles the 16-chain groups [group0, group0+ngroups) of
+                                   ceil(B*S/16); ngroups = 0 means all.  Chains never interact, so a pass may be issued
+                                   in pieces on different streams; partial/slab buffers keep their full-size layout.  */
     double k_factor;            /* config['k_factor']       cbfssm.py:191,214                                */
 } cbfssm_problem;
 

@@ -103,3 +103,29 @@ def test_grad_stash_mode_matches_oracle(kw, gib):
     scal, gref = tref.loss_and_grads(cfg, p, u, y, noise, True)
     assert float(loss) == pytest.approx(scal['loss'], rel=1e-9)
     _check(grads, gref)
+
+
+def test_chain_group_split_is_bitwise_identical(monkeypatch):
+    """The two-stream chain-group split (hip/train.py:_split) must not change a single bit: chains are independent and
+    every partial sum keeps its slot."""
+    w = syn.tiny(M=20, T=19, B=5, S=11, recog_len=3)          # 55 chains = 4 groups of 16 (last one ragged)
+    cfg = w.model_config()
+    p = syn.perturb_params(syn.make_params(w))
+    u, y = syn.make_inputs(w)
+    noise = syn.make_noise(w)
+    params = {k: torch.tensor(v, device=DEV) for k, v in p.items()}
+    monkeypatch.setenv('CBFSSM_NO_SPLIT', '1')
+    eng = train.HipElboGrad(cfg, DEV)
+    l0, g0, _ = eng.loss_and_grads(params, u, y, noise)
+    le0, _, ws0 = eng.forward(params, u, y, noise)
+    x0 = ws0.x.clone()
+    monkeypatch.delenv('CBFSSM_NO_SPLIT')
+    for main in (1, 3):
+        monkeypatch.setenv('CBFSSM_SPLIT_MAIN', str(main))
+        eng2 = train.HipElboGrad(cfg, DEV)
+        l1, g1, _ = eng2.loss_and_grads(params, u, y, noise)
+        le1, _, ws1 = eng2.forward(params, u, y, noise)
+        assert float(l1) == float(l0) and float(le1) == float(le0)
+        assert torch.equal(ws1.x, x0)
+        for k in train.PARAM_NAMES:
+            assert torch.equal(g0[k], g1[k]), (main, k)
