@@ -110,12 +110,12 @@ def main():
     y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=dev, generator=g)
     params = {k: torch.tensor(v, device=dev) for k, v in syn.make_params(w, seed=1).items()}
     N = w.N
-    noise_buf = torch.empty(2 * w.T * N * 2 + (w.T - 1) * N, dtype=torch.float64, device=dev)
+    # fresh noise every step (the reference draws it inside the graph); the draw for step k+1 runs on a side stream
+    # while step k computes
+    noise_pipe = ops.NoisePipeline(dev, g)
 
     def draw_noise():
-        noise_buf.normal_(generator=g)
-        a = 2 * w.T * N
-        return {'hid_b': noise_buf[:a], 'eps_b': noise_buf[a:2 * a], 'eps_f': noise_buf[2 * a:]}
+        return noise_pipe.next(w.T, N)
 
     red = torch.zeros(8, dtype=torch.float64, device=dev)
     if mode == 'train':

@@ -218,3 +218,45 @@ class HipElbo:
         elbo_forward(prob, self.pack_f, self.pack_b, self.var_x, self.var_y, u, y, hid_b, eps_b, eps_f,
                      self.config['loss_factors'], ws)
         return ws
+
+
+class NoisePipeline:
+    """Standard-normal draws for the next ELBO evaluation, generated on a side stream while the current evaluation
+    runs (the noise does not depend on the parameters): two buffers, one being consumed, one being filled.
+    One normal per (b, s) and step, as the reference tiles it (cbfssm.py:134,149,209)."""
+
+    def __init__(self, device, generator=None, with_backward=True):
+        self.device = torch.device(device)
+        self.gen = generator
+        self.with_backward = with_backward
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._bufs = {}
+        self._ready = {}       # key -> (index of the buffer that holds / is receiving fresh noise, event)
+
+    def _numel(self, T, N):
+        return (4 * T * N if self.with_backward else 0) + (T - 1) * N
+
+    def _fill(self, key, idx):
+        buf = self._bufs[key][idx]
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)          # the buffer's previous consumer (issued on `cur`) must be done
+        with torch.cuda.stream(self.stream):
+            buf.normal_(generator=self.gen)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._ready[key] = (idx, ev)
+
+    def next(self, T, N):
+        key = (T, N)
+        if key not in self._bufs:
+            n = self._numel(T, N)
+            self._bufs[key] = [torch.empty(n, dtype=torch.float64, device=self.device) for _ in range(2)]
+            self._fill(key, 0)
+        idx, ev = self._ready[key]
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        buf = self._bufs[key][idx]
+        self._fill(key, 1 - idx)               # start the draw for the next call
+        if self.with_backward:
+            a = 2 * T * N
+            return {'hid_b': buf[:a], 'eps_b': buf[a:2 * a], 'eps_f': buf[2 * a:]}
+        return {'eps_f': buf}

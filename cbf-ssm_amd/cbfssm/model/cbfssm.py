@@ -117,13 +117,13 @@ class CBFSSM(BaseModel):
         dev = self._device
         self._opt.load_state_dict({'flat': sd['flat'].to(dev), 'm': sd['m'].to(dev), 'v': sd['v'].to(dev), 't': sd['t']})
 
+    _noise_with_backward = True
+
     def _draw_noise(self, B, T):
-        S = self.config['samples']
-        N = B * S
-        buf = torch.empty(4 * T * N + (T - 1) * N, dtype=torch.float64, device=self._device)
-        buf.normal_(generator=self._gen)
-        a = 2 * T * N
-        return {'hid_b': buf[:a], 'eps_b': buf[a:2 * a], 'eps_f': buf[2 * a:]}
+        from ..hip.ops import NoisePipeline
+        if getattr(self, '_noise', None) is None:
+            self._noise = NoisePipeline(self._device, self._gen, self._noise_with_backward)
+        return self._noise.next(T, B * self.config['samples'])
 
     # ---- one sess.run
     def _execute(self, sess, names, feed):

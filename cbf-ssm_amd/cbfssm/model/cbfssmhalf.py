@@ -47,8 +47,4 @@ class CBFSSMHALF(CBFSSM):
         from ..hip.train_half import HipHalfGrad, half_param_names
         return HipHalfGrad(self.config, sess.device, dist), half_param_names(self.config)
 
-    def _draw_noise(self, B, T):
-        N = B * self.config['samples']
-        eps = torch.empty((T - 1) * N, dtype=torch.float64, device=self._device)
-        eps.normal_(generator=self._gen)
-        return {'eps_f': eps}
+    _noise_with_backward = False
