@@ -375,7 +375,7 @@ class HipElboGrad:
             seg0 = seg1
         return gB_f, gB_b
 
-    def _gp_adjoint(self, pack, slab, Z, ls, var, zmean, zvar, Do, gB_stash=None):
+    def _gp_adjoint(self, pack, slab, Z, ls, var, zmean, zvar, Do, gB_stash=None, kl_pack=None):
         """Adjoint of gp_prepare (K_mm -> chol -> K^-1, operand scaling, prior KL) given the reduced data slab."""
         lay = pack.layout
         M, D, NBLK, JB = self.M, self.D, lay.NBLK, lay.JB
@@ -397,12 +397,17 @@ class HipElboGrad:
         gZt = gZf[:M, :D] - Zs * gZf[:M, D:D + 1]           # Ebar x~^T - z~ o rowsum(Ebar)
         glx = small[32:32 + D]
         gsig, glogsig = small[96], small[97]
-        # prior KL (gp_tf.py:163-172), weight 1 in the loss, added once (rank invariant)
-        gmu = gmu + Kinv @ zmean
-        gs2 = gs2 + 0.5 * (torch.diagonal(Kinv)[:, None] - 1.0 / zvar)
-        gB = gB + 0.5 * (torch.diag(zvar.sum(1)) + zmean @ zmean.T)
+        # prior KL (gp_tf.py:163-172), weight 1 in the loss, added once (rank invariant).  PR-SSM factorises the prior
+        # without jitter (prssm.py:81-82): its KL terms then use the jitter-free inverse of kl_pack.
+        Kkl = kl_pack.Kinv if kl_pack is not None else Kinv
+        gmu = gmu + Kkl @ zmean
+        gs2 = gs2 + 0.5 * (torch.diagonal(Kkl)[:, None] - 1.0 / zvar)
+        gB_kl = 0.5 * (torch.diag(zvar.sum(1)) + zmean @ zmean.T)
         # K^-1 = (K_mm + jitter I)^-1 ; log det term of the KL: d/dK (0.5 Do log det K) = 0.5 Do K^-1
-        gK = -(Kinv @ gB @ Kinv) + 0.5 * Do * Kinv
+        if kl_pack is None:
+            gK = -(Kinv @ (gB + gB_kl) @ Kinv) + 0.5 * Do * Kinv
+        else:
+            gK = -(Kinv @ gB @ Kinv) - (Kkl @ gB_kl @ Kkl) + 0.5 * Do * Kkl
         # K = var * exp(-0.5 d2(z~))                                           (gp_tf.py:33-49)
         gKK = gK * Kmm
         gvar = gKK.sum() / var[0] + gsig + glogsig / var[0]

@@ -23,11 +23,33 @@ RECOG_NAMES = ('recog.gate_kernel', 'recog.gate_bias', 'recog.cand_kernel', 'rec
 GRU_UNITS = 16      # cbfssmhalf.py:84
 
 
-def half_param_names(config):
-    names = GP_NAMES + ('var_x_unc', 'var_y_unc')
-    if config.get('recog_model', 'rnn') == 'rnn':
+CONV_NAMES = ('recog.conv_kernel', 'recog.conv_bias', 'recog.dense_kernel', 'recog.dense_bias')
+PRSSM_GP_NAMES = ('zeta_pos', 'zeta_mean', 'zeta_var_unc', 'variance_unc', 'lengthscales_unc')
+
+
+def half_param_names(config, variant='half'):
+    if variant == 'prssm':
+        names = PRSSM_GP_NAMES + ('var_x_unc', 'var_y_unc')
+        recog = config['recog_model']
+    else:
+        names = GP_NAMES + ('var_x_unc', 'var_y_unc')
+        recog = config.get('recog_model', 'rnn')
+    if recog == 'rnn':
         names = names + RECOG_NAMES
+    elif recog == 'conv':
+        names = names + CONV_NAMES
     return names
+
+
+def conv_recognition(recog, u, y, recog_len):
+    """prssm.py:143-155: conv1d(5, 3, relu) -> max_pool(2, 2) -> dense, in float32 as the reference casts it."""
+    uy = torch.cat((u, y), dim=2)[:, :recog_len, :].to(torch.float32)
+    k = recog['recog.conv_kernel'].to(torch.float32)                      # TF layout (width, in, out)
+    x = torch.nn.functional.conv1d(uy.permute(0, 2, 1), k.permute(2, 1, 0), recog['recog.conv_bias'].to(torch.float32))
+    x = torch.nn.functional.max_pool1d(torch.relu(x), 2, 2)
+    x = x.permute(0, 2, 1).reshape(u.shape[0], -1)
+    out = x @ recog['recog.dense_kernel'].to(torch.float32) + recog['recog.dense_bias'].to(torch.float32)
+    return out.to(torch.float64)
 
 
 def gru_recognition(recog, u, y, recog_len):
@@ -46,15 +68,25 @@ def gru_recognition(recog, u, y, recog_len):
 class HipHalfGrad:
     """loss and gradients of CBFSSMHALF for one mini-batch on one device."""
 
-    def __init__(self, config, device, dist=None):
+    def __init__(self, config, device, dist=None, variant='half'):
+        """variant 'half': CBFSSMHALF.  variant 'prssm': the PR-SSM baseline (reference cbfssm/model/prssm.py) -- the same
+        pass with the Kalman update switched off everywhere (free run), loss = -(lambda0 * loglik - KL_z) with the KL
+        prior factorised WITHOUT jitter (prssm.py:81-82,96) and one shared lengthscale (prssm.py:40)."""
         self.config = config
+        self.variant = variant
         self.device = torch.device(device)
         self.dist = dist
         self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
         self.M, self.S = config['ind_pnt_num'], config['samples']
         self.D = self.dim_x + self.dim_u
-        self.names = half_param_names(config)
+        self.names = half_param_names(config, variant)
         self.rnn = 'recog.gate_kernel' in self.names
+        self.conv = 'recog.conv_kernel' in self.names
+        self.pre = '' if variant == 'prssm' else 'f.'
+        # loss = -(cL * (loglik - kl_x) - KL_z): cL = lambda0 / S for CBFSSMHALF, lambda0 for PR-SSM
+        lf0 = float(config['loss_factors'][0])
+        self.cL = lf0 if variant == 'prssm' else lf0 / self.S
+        self.pack_kl = GPPack(self.M, self.D, self.dim_x, self.device) if variant == 'prssm' else None
         self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device)
         self.stash = bool(self.pack_f.layout.rev_stash)
         self.stash_bytes = int(float(config.get('adjoint_stash_gib', 4.0)) * 2 ** 30)
@@ -67,12 +99,24 @@ class HipHalfGrad:
 
     def _problem(self, B, T, condition):
         c = self.config
+        if self.variant == 'prssm':      # never condition: recog_len 1 and condition False make every step a free run
+            return _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, 1, 1.0, False, half=True)
         return _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, c['recog_len'], c['k_factor'],
                                condition, half=True)
 
-    def _x0(self, p, u, y):
+    def _recog_params(self, p):
         if self.rnn:
-            return gru_recognition(p, u, y, self.config['recog_len'])
+            return RECOG_NAMES
+        return CONV_NAMES if self.conv else ()
+
+    def _recog(self, rp, u, y):
+        if self.rnn:
+            return gru_recognition(rp, u, y, self.config['recog_len'])
+        return conv_recognition(rp, u, y, self.config['recog_len'])
+
+    def _x0(self, p, u, y):
+        if self.rnn or self.conv:
+            return self._recog(p, u, y)
         B = u.shape[0]
         return torch.cat((y[:, 0, :], torch.zeros(B, self.dim_x - self.dim_y, dtype=u.dtype, device=u.device)), dim=1)
 
@@ -80,7 +124,10 @@ class HipHalfGrad:
         lib = _l.load()
         st = _stream()
         pb = C.byref(prob)
-        self.pack_f.prepare(p['f.zeta_pos'], c['ls'], c['var'], p['f.zeta_mean'], c['zvar'])
+        pre = self.pre
+        self.pack_f.prepare(p[pre + 'zeta_pos'], c['ls'], c['var'], p[pre + 'zeta_mean'], c['zvar'])
+        if self.pack_kl is not None:
+            self.pack_kl.prepare(p[pre + 'zeta_pos'], c['ls'], c['var'], p[pre + 'zeta_mean'], c['zvar'], jitter=0.0)
         lay = C.byref(self.pack_f.layout)
         rc = lib.cbfssm_half_forward_pass_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
                                               _ptr(u), _ptr(y), _ptr(x0), _ptr(eps_f) if eps_f.numel() else None,
@@ -89,15 +136,19 @@ class HipHalfGrad:
         rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(c['var_y']), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part),
                                            _ptr(ws.pred_mean), _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)
         _l.check(rc, 'cbfssm_loglik_moments_f64')
-        lf = self.config['loss_factors']
-        rc = lib.cbfssm_elbo_combine_f64(pb, float(lf[0]), 0.0, _ptr(ws.ll_part), ws.ll_part.numel(), _ptr(ws.kl_part),
-                                         ws.kl_part.numel(), None, 0, _ptr(self.pack_f.scal), None, _ptr(ws.out), st)
+        klp = self.pack_kl if self.pack_kl is not None else self.pack_f
+        rc = lib.cbfssm_elbo_combine_f64(pb, self.cL * self.S, 0.0, _ptr(ws.ll_part), ws.ll_part.numel(), _ptr(ws.kl_part),
+                                         ws.kl_part.numel(), None, 0, _ptr(klp.scal), None, _ptr(ws.out), st)
         _l.check(rc, 'cbfssm_elbo_combine_f64')
 
     def _constrained(self, p):
-        return {'ls': tf_forward(p['f.lengthscales_unc']).reshape(-1).contiguous(),
-                'var': tf_forward(p['f.variance_unc']).reshape(-1).contiguous(),
-                'zvar': tf_forward(p['f.zeta_var_unc']).contiguous(),
+        pre = self.pre
+        ls = tf_forward(p[pre + 'lengthscales_unc']).reshape(-1)
+        if ls.numel() == 1:                                  # PR-SSM: one lengthscale for all input dims (prssm.py:40)
+            ls = ls.expand(self.D)
+        return {'ls': ls.contiguous(),
+                'var': tf_forward(p[pre + 'variance_unc']).reshape(-1).contiguous(),
+                'zvar': tf_forward(p[pre + 'zeta_var_unc']).contiguous(),
                 'var_x': tf_forward(p['var_x_unc']).contiguous(), 'var_y': tf_forward(p['var_y_unc']).contiguous()}
 
     def _workspace(self, prob):
@@ -130,8 +181,7 @@ class HipHalfGrad:
 
     def _terms(self, ws, red2=None):
         out = ws.out
-        lf = self.config['loss_factors']
-        cL = float(lf[0]) / self.S
+        cL = self.cL
         if red2 is None:
             loglik, kl_x = out[0], out[1]
         else:
@@ -169,9 +219,10 @@ class HipHalfGrad:
         c = self._constrained(p)
         eps_f = _f64(noise['eps_f'], dev)
         rp = {}
-        if self.rnn:
-            rp = {k: p[k].detach().clone().requires_grad_(True) for k in RECOG_NAMES}
-            x0g = gru_recognition(rp, u, y, self.config['recog_len'])
+        rnames = self._recog_params(p)
+        if rnames:
+            rp = {k: p[k].detach().clone().requires_grad_(True) for k in rnames}
+            x0g = self._recog(rp, u, y)
             x0 = x0g.detach().contiguous()
         else:
             x0 = self._x0(p, u, y).contiguous()
@@ -179,8 +230,7 @@ class HipHalfGrad:
 
         st = _stream()
         pb = C.byref(prob)
-        lf = self.config['loss_factors']
-        cL = float(lf[0]) / self.S
+        cL = self.cL
         sf = self.slab_f
         red = ws.red
         lay = C.byref(self.pack_f.layout)
@@ -232,9 +282,9 @@ class HipHalfGrad:
         tail[2:] = -cL * 0.5 * (sq_d / (vy * vy) - B * T * self.S / vy)
         gx0_b = ws.gx0.view(B, self.S, self.dim_x).sum(1)        # d loss / d x_0 per sequence (tiled over S, :87)
         rgrads = {}
-        if self.rnn:
-            gl = torch.autograd.grad(x0g, [rp[k] for k in RECOG_NAMES], grad_outputs=gx0_b)
-            rgrads = dict(zip(RECOG_NAMES, gl))
+        if rnames:
+            gl = torch.autograd.grad(x0g, [rp[k] for k in rnames], grad_outputs=gx0_b)
+            rgrads = dict(zip(rnames, gl))
         if self.dist is not None:
             all_reduce_sum(red, self.dist)
             if gB is not None:
@@ -243,13 +293,17 @@ class HipHalfGrad:
                 all_reduce_sum(rgrads[k], self.dist)
 
         grads = dict(rgrads)
-        gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(self.pack_f, red[:sf], p['f.zeta_pos'], c['ls'], c['var'],
-                                                          p['f.zeta_mean'], c['zvar'], self.dim_x, gB)
-        grads['f.zeta_pos'] = gz
-        grads['f.zeta_mean'] = gmu
-        grads['f.zeta_var_unc'] = gs2 * torch.sigmoid(p['f.zeta_var_unc'])
-        grads['f.variance_unc'] = (gvar * torch.sigmoid(p['f.variance_unc'])).reshape(p['f.variance_unc'].shape)
-        grads['f.lengthscales_unc'] = gls * torch.sigmoid(p['f.lengthscales_unc'])
+        pre = self.pre
+        gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(self.pack_f, red[:sf], p[pre + 'zeta_pos'], c['ls'], c['var'],
+                                                          p[pre + 'zeta_mean'], c['zvar'], self.dim_x, gB, self.pack_kl)
+        grads[pre + 'zeta_pos'] = gz
+        grads[pre + 'zeta_mean'] = gmu
+        grads[pre + 'zeta_var_unc'] = gs2 * torch.sigmoid(p[pre + 'zeta_var_unc'])
+        grads[pre + 'variance_unc'] = (gvar * torch.sigmoid(p[pre + 'variance_unc'])).reshape(p[pre + 'variance_unc'].shape)
+        lsu = p[pre + 'lengthscales_unc']
+        if lsu.numel() == 1:
+            gls = gls.sum().reshape(lsu.shape)               # shared lengthscale: its adjoint is the sum over the dims
+        grads[pre + 'lengthscales_unc'] = gls * torch.sigmoid(lsu)
         grads['var_x_unc'] = small[0:self.dim_x] * torch.sigmoid(p['var_x_unc'])
         grads['var_y_unc'] = (small[16:16 + self.dim_y] + tail[2:]) * torch.sigmoid(p['var_y_unc'])
         loss, terms = self._terms(ws, tail[0:2])

@@ -1,10 +1,11 @@
 """cbfssm.model: the CBF-SSM model class on the MI355X HIP path.
 
-CBFSSM and its forward-only variant CBFSSMHALF run on the HIP kernels.  The reference also ships PRSSM and Voliro
-(cbfssm/model/__init__.py:3-4); they are outside the hot path this build accelerates and raise
-a clear error instead of silently falling back."""
+CBFSSM, its forward-only variant CBFSSMHALF and the PR-SSM baseline run on the HIP kernels.  The reference also ships
+Voliro (cbfssm/model/__init__.py:4: a hexacopter physics model on a proprietary dataset); it is outside the hot path
+this build accelerates and raises a clear error instead of silently falling back."""
 from .cbfssm import CBFSSM
 from .cbfssmhalf import CBFSSMHALF
+from .prssm import PRSSM
 from .session import Session, OutOfRangeError, InvalidArgumentError
 
 
@@ -17,5 +18,4 @@ def _not_built(name):
     return _Missing
 
 
-PRSSM = _not_built('PRSSM')
 Voliro = _not_built('Voliro')

@@ -252,3 +252,80 @@ def half_loss_and_grads(config, params_np, u_np, y_np, noise_np, condition=True)
     out['loss'].backward()
     return float(out['loss'].detach()), {k: (v.grad.detach().numpy().copy() if v.grad is not None else np.zeros(v.shape))
                                 for k, v in params.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cbfssm/model/prssm.py  (PR-SSM baseline: free-running forward pass, ELBO = lambda0 * loglik - KL_z)
+# ---------------------------------------------------------------------------------------------------------------------
+def conv_recognition(recog, u, y, recog_len):
+    """prssm.py:143-155: conv1d(5 filters, width 3, relu) -> max_pool(2,2) -> dense, computed in float32."""
+    uy = torch.cat((u, y), dim=2)[:, :recog_len, :].to(torch.float32)                     # (B, L, C)
+    k = recog['conv_kernel'].to(torch.float32)                                            # (3, C, 5) TF layout
+    x = torch.nn.functional.conv1d(uy.permute(0, 2, 1), k.permute(2, 1, 0), recog['conv_bias'].to(torch.float32))
+    x = torch.relu(x)                                                                     # (B, 5, L-2)
+    x = torch.nn.functional.max_pool1d(x, 2, 2)                                           # (B, 5, (L-2)//2)
+    x = x.permute(0, 2, 1).reshape(u.shape[0], -1)                                        # TF flattens (time, channel)
+    out = x @ recog['dense_kernel'].to(torch.float32) + recog['dense_bias'].to(torch.float32)
+    return out.to(torch.float64)
+
+
+def prssm_elbo_step(config, params, u, y, noise):
+    """cbfssm/model/prssm.py:19-130 on float64 CPU tensors."""
+    dim_u, dim_y, dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
+    S = config['samples']
+    lf = config['loss_factors']
+    B, T, _ = u.shape
+    p = params
+    M = p['zeta_pos'].shape[0]
+    zeta_var = tf_forward(p['zeta_var_unc'])
+    var_x, var_y = tf_forward(p['var_x_unc']), tf_forward(p['var_y_unc'])
+    kern = RBF(p['variance_unc'], p['lengthscales_unc'])                                  # scalar lengthscale, :40
+    recog = config['recog_model']
+    rp = {k[6:]: v for k, v in p.items() if k.startswith('recog.')}
+    if recog == 'output':
+        x0 = torch.cat((y[:, 0, :], torch.zeros(B, dim_x - dim_y, dtype=u.dtype)), dim=1)
+    elif recog == 'conv':
+        x0 = conv_recognition(rp, u, y, config['recog_len'])
+    else:
+        x0 = gru_recognition(rp, u, y, config['recog_len'])
+    # conditional() with Lm=None: jittered Cholesky per call (gp_tf.py:68-100) -- loop invariant
+    Lm = torch.linalg.cholesky(kern.K(p['zeta_pos']) + JITTER * torch.eye(M, dtype=u.dtype))
+    q_sqrt = torch.sqrt(zeta_var)
+    xs = [x0[:, None, :].repeat(1, S, 1)]
+    for t in range(T - 1):
+        u_t = u[:, t, None, :].repeat(1, S, 1)
+        in_t = torch.cat((xs[t], u_t), dim=2).reshape(B * S, dim_u + dim_x)
+        Kmn = kern.K(p['zeta_pos'], in_t)
+        A = torch.linalg.solve_triangular(Lm, Kmn, upper=False)
+        fvar = torch.squeeze(kern.variance) - torch.sum(torch.square(A), 0)
+        fvar = fvar[None, :].repeat(dim_x, 1)
+        A = torch.linalg.solve_triangular(Lm.T, A, upper=True)
+        fmean = A.T @ p['zeta_mean']
+        LTA = A[None, :, :] * q_sqrt.T[:, :, None]
+        fvar = (fvar + torch.sum(torch.square(LTA), 1)).T
+        fmean = fmean.reshape(B, S, dim_x) + xs[t]
+        fvar = fvar.reshape(B, S, dim_x) + var_x
+        eps = noise['eps_f'][t][:, :, None].repeat(1, 1, dim_x)
+        xs.append(fmean + eps * torch.sqrt(fvar))                                          # prssm.py:122-125
+    x_final = torch.stack(xs).permute(1, 0, 2, 3)
+    y_final = x_final[..., :dim_y]
+    loglik = torch.sum(torch.distributions.Normal(y_final, torch.sqrt(var_y)).log_prob(y[:, :, None, :]))
+    # KL regulariser: prior Cholesky WITHOUT jitter (prssm.py:81-82)
+    D = torch.distributions
+    prior = D.MultivariateNormal(torch.zeros(dim_x, M, dtype=u.dtype),
+                                 scale_tril=torch.linalg.cholesky(kern.K(p['zeta_pos']))[None].repeat(dim_x, 1, 1))
+    post = D.MultivariateNormal(p['zeta_mean'].T, scale_tril=torch.diag_embed(torch.sqrt(zeta_var).T))
+    kl_reg = torch.sum(D.kl_divergence(post, prior))
+    elbo = loglik * float(lf[0]) - kl_reg                                                  # prssm.py:96
+    return {'loss': -elbo, 'loglik': loglik, 'kl_z': kl_reg, 'x_final': x_final,
+            'pred_mean': torch.mean(y_final, dim=2), 'pred_var': torch.var(y_final, dim=2, unbiased=False) + var_y}
+
+
+def prssm_loss_and_grads(config, params_np, u_np, y_np, noise_np):
+    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params_np.items()}
+    noise = {k: torch.tensor(v, dtype=torch.float64) for k, v in noise_np.items()}
+    out = prssm_elbo_step(config, params, torch.tensor(u_np), torch.tensor(y_np), noise)
+    out['loss'].backward()
+    res = {k: v.detach().numpy() for k, v in out.items()}
+    return res, {k: (v.grad.detach().numpy().copy() if v.grad is not None else np.zeros(v.shape))
+                 for k, v in params.items()}

@@ -6,7 +6,7 @@ import pytest
 from cbfssm.model.base_model import shuffle_order, BaseModel
 from cbfssm.model.session import OutOfRangeError
 from cbfssm.datasets import BaseDS, make_synthetic_ds, Sarcos, Actuator, RoboMove
-from cbfssm.model import CBFSSM, CBFSSMHALF, PRSSM
+from cbfssm.model import CBFSSM, CBFSSMHALF, PRSSM, Voliro
 from cbfssm import synthetic as syn
 
 
@@ -98,7 +98,15 @@ def test_model_surface_without_gpu():
     assert np.all(np.abs(iv['f.zeta_pos']) <= cfg['zeta_pos'])
     np.testing.assert_allclose(np.logaddexp(0, iv['var_x_unc']) + 1e-10, cfg['var_x'], rtol=1e-9)
     with pytest.raises(NotImplementedError):
-        PRSSM(cfg)
+        Voliro(cfg)
+    pcfg = dict(cfg)
+    pcfg['var_y'] = np.asarray([0.3 ** 2] * w.dim_y)
+    pcfg['recog_model'] = 'conv'
+    pcfg['recog_len'] = 16
+    pm = PRSSM(pcfg)
+    assert pm._init_values['recog.dense_kernel'].shape == (35, w.dim_x) and pm._init_values['lengthscales_unc'].shape == (1,)
+    assert set(pm.var_dict) == {'process noise', 'observation noise', 'kernel lengthscales', 'kernel variance', 'IP pos',
+                                'IP mean', 'IP var'}
     hcfg = dict(cfg)
     hcfg['var_y'] = np.asarray([0.3 ** 2] * w.dim_y)
     h = CBFSSMHALF(hcfg)

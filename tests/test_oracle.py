@@ -218,3 +218,58 @@ def test_half_numpy_matches_torch_and_fd(recog):
             fd = (orc.CBFSSMHALFOracle(cfg, pp).run(u, y, noise)['loss']
                   - orc.CBFSSMHALFOracle(cfg, pm).run(u, y, noise)['loss']) / (2 * h)
             assert grads[name].reshape(-1)[idx] == pytest.approx(fd, rel=5e-5, abs=1e-6), (name, idx)
+
+
+# ---- PR-SSM restatement (cbfssm/model/prssm.py): free run == CBFSSMHALF with conditioning off; gradient vs FD
+def _prssm_setup(recog='rnn', **kw):
+    w = syn.tiny(**kw)
+    cfg = w.model_config()
+    cfg['var_y'] = np.asarray([w.var_y] * w.dim_y)
+    cfg['recog_model'] = recog
+    rng = np.random.default_rng(6)
+    base = syn.perturb_params(syn.make_params(w, seed=1))
+    p = {k[2:]: v for k, v in base.items() if k.startswith('f.') and 'lengthscales' not in k}
+    p['lengthscales_unc'] = syn.softplus_inverse(np.asarray([w.gp_len])) + 0.1
+    p['var_x_unc'] = base['var_x_unc']
+    p['var_y_unc'] = syn.softplus_inverse(cfg['var_y']) + 0.1 * rng.standard_normal(w.dim_y)
+    n_in, H = w.dim_u + w.dim_y, 16
+    if recog == 'rnn':
+        p.update({'recog.gate_kernel': 0.3 * rng.standard_normal((n_in + H, 2 * H)), 'recog.gate_bias': np.ones(2 * H),
+                  'recog.cand_kernel': 0.3 * rng.standard_normal((n_in + H, H)), 'recog.cand_bias': 0.1 * rng.standard_normal(H),
+                  'recog.dense_kernel': 0.3 * rng.standard_normal((H, w.dim_x)), 'recog.dense_bias': 0.1 * rng.standard_normal(w.dim_x)})
+    elif recog == 'conv':
+        flat = 5 * ((w.recog_len - 2) // 2)
+        p.update({'recog.conv_kernel': 0.4 * rng.standard_normal((3, n_in, 5)), 'recog.conv_bias': 0.1 * rng.standard_normal(5),
+                  'recog.dense_kernel': 0.3 * rng.standard_normal((flat, w.dim_x)), 'recog.dense_bias': 0.1 * rng.standard_normal(w.dim_x)})
+    u, y = syn.make_inputs(w)
+    noise = {'eps_f': syn.make_noise(w)['eps_f']}
+    return w, cfg, p, u, y, noise
+
+
+def test_prssm_is_half_without_conditioning_and_fd():
+    w, cfg, p, u, y, noise = _prssm_setup('output', T=6, B=2, S=3, M=6, recog_len=3)
+    res, grads = tref.prssm_loss_and_grads(cfg, p, u, y, noise)
+    # the numpy CBFSSMHALF oracle with condition=False and recog_len=1 free-runs from the same x_0
+    hp = {'f.' + k: v for k, v in p.items() if k in ('zeta_pos', 'zeta_mean', 'zeta_var_unc', 'variance_unc')}
+    hp['f.lengthscales_unc'] = np.tile(p['lengthscales_unc'], w.D)
+    hp['var_x_unc'], hp['var_y_unc'] = p['var_x_unc'], p['var_y_unc']
+    hcfg = dict(cfg)
+    hcfg['recog_len'] = 1
+    half = orc.CBFSSMHALFOracle(hcfg, hp).run(u, y, noise, condition=False)
+    np.testing.assert_allclose(res['x_final'], half['x_final'], rtol=1e-10, atol=1e-12)
+    assert half['kl_x'] == 0.0
+    assert float(res['loglik']) == pytest.approx(half['loglik'], rel=1e-10)
+    # the prior KL without jitter differs from the jittered one only at the 1e-8 level here
+    assert float(res['kl_z']) == pytest.approx(half['kl_z_f'], rel=1e-5)
+    rng = np.random.default_rng(3)
+    for name in p:
+        flat = p[name].reshape(-1)
+        for idx in rng.choice(flat.size, size=min(2, flat.size), replace=False):
+            h = 1e-6 * max(1.0, abs(flat[idx]))
+            pp = {k: v.copy() for k, v in p.items()}
+            pm = {k: v.copy() for k, v in p.items()}
+            pp[name].reshape(-1)[idx] += h
+            pm[name].reshape(-1)[idx] -= h
+            fd = (float(tref.prssm_loss_and_grads(cfg, pp, u, y, noise)[0]['loss'])
+                  - float(tref.prssm_loss_and_grads(cfg, pm, u, y, noise)[0]['loss'])) / (2 * h)
+            assert grads[name].reshape(-1)[idx] == pytest.approx(fd, rel=5e-5, abs=1e-6), (name, idx)
