@@ -130,6 +130,9 @@ class ElboWorkspace:
         self.n_kl = int(lib.cbfssm_forward_pass_partials(C.byref(p)))
         self.y2 = torch.zeros(T, N, dob, **f)
         self.h_all = torch.zeros(2, T, N, dob, **f) if keep_h else None
+        # every step's (fmean, fvar): the adjoint reads them instead of recomputing the predictive products
+        self.fmv_b = torch.zeros(2, T, N, dob, 2, **f) if keep_h else None
+        self.fmv_f = torch.zeros(max(T - 1, 0), N, p.dim_x, 2, **f) if keep_h else None
         self.x = torch.zeros(T, N, p.dim_x, **f)
         self.ent_part = torch.zeros(self.n_ent, **f)
         self.kl_part = torch.zeros(self.n_kl, **f)
@@ -158,11 +161,12 @@ def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, 
     assert hid_b.numel() == 2 * prob.T * N and eps_b.numel() == 2 * prob.T * N
     assert eps_f.numel() == (prob.T - 1) * N
     rc = lib.cbfssm_backward_pass_f64(pb, C.byref(pack_b.layout), _ptr(pack_b.buf), _ptr(var_x), _ptr(u), _ptr(y),
-                                      _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.ent_part), st)
+                                      _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.fmv_b),
+                                      _ptr(ws.ent_part), st)
     _l.check(rc, 'cbfssm_backward_pass_f64')
     rc = lib.cbfssm_forward_pass_f64(pb, C.byref(pack_f.layout), _ptr(pack_f.buf), _ptr(var_x), _ptr(var_y),
                                      _ptr(u), _ptr(y), _ptr(ws.y2), _ptr(eps_f) if eps_f.numel() else None,
-                                     _ptr(ws.x), _ptr(ws.kl_part), st)
+                                     _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.kl_part), st)
     _l.check(rc, 'cbfssm_forward_pass_f64')
     rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(var_y), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part), _ptr(ws.pred_mean),
                                        _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)

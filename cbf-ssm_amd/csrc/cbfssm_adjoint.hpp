@@ -61,6 +61,7 @@ struct RevArgs {
     int half;              // CBFSSMHALF forward pass
     double* gx0;           // half: (N, dim_x) d loss / d x_0 per chain (summed over the particles by the caller)
     int group0, gtotal;    // this launch covers chain groups [group0, group0 + gridDim.x) of gtotal
+    const double* fmv;     // (fmean, fvar) of every step as saved by the forward evaluation (PassArgs::fmv layout)
 };
 
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
@@ -276,108 +277,27 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
             }
         }
-        CBF_STAMP_BARRIER(0);
-
-        // ---- B: kernel tile (rows of this wave)
-        double bx[DK], xx = 0.0;
+        double fmv_m[QPW], fmv_v[QPW];
 #pragma unroll
-        for (int s = 0; s < DK; ++s) {
-            bx[s] = xq[(4 * s + g) * PD + nl];
-            xx = fma(bx[s], bx[s], xx);
-        }
-        xx += __shfl_xor(xx, 16);
-        xx += __shfl_xor(xx, 32);
-        d4 kreg[RB];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            kreg[i] = d4{0, 0, 0, 0};
-            if (ok[i]) {
-                d4 e;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) e[r] = tile.czr[i][r] - 0.5 * xx;
-#pragma unroll
-                for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[i][s], bx[s], e);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    kreg[i][r] = exp(e[r]);
-                    Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
-                }
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int d = 4 * (w + qi * W) + g;
+            fmv_m[qi] = 0.0; fmv_v[qi] = 1.0;
+            if (act[qi]) {
+                const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
+                fmv_m[qi] = o[0]; fmv_v[qi] = o[1];
             }
         }
-        CBF_STAMP_BARRIER(1);
-
-        // ---- C: A2 rows of this wave, P1/P2
-        CBF_STAMP_MARK0();
-        d4 a2[RB];
-        {
-            d4 acc[RB][2];
-#pragma unroll
-            for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
-            int s = 0;
-#pragma unroll 2
-            for (; s + 1 < KSr; s += 2) {
-                const double b0 = Kt[(4 * s + g) * PD + nl], b1 = Kt[(4 * s + 4 + g) * PD + nl];
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    if (ok[i]) {
-                        acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
-                        acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
-                    }
-                }
-            }
-            if (s < KSr) {
-                const double b0 = Kt[(4 * s + g) * PD + nl];
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-                    if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
-            }
-#pragma unroll
-            for (int i = 0; i < RB; ++i) a2[i] = acc[i][0] + acc[i][1];
-        }
-        CBF_STAMP_MARK(0);
-        {
-            d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
-            double q = 0.0;
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                if (ok[i]) {
-                    const double* mAp = a.pk.muA + rbs[i] * 256 + l;
-                    const double* sAp = a.pk.s2A + rbs[i] * 256 + l;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        P1 = CBF_MFMA(mAp[r * 64], a2[i][r], P1);
-                        P2 = CBF_MFMA(sAp[r * 64], a2[i][r] * a2[i][r], P2);
-                        q = fma(kreg[i][r], a2[i][r], q);
-                    }
-                }
-            }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                part[w * PSL + (0 * 4 + r) * 64 + l] = P1[r];
-                part[w * PSL + (1 * 4 + r) * 64 + l] = P2[r] - q;
-            }
-        }
-        CBF_STAMP_MARK(1);
-        CBF_STAMP_BARRIER(2);
-
-        // ---- D: adjoint of the step epilogue
+        // ---- D: adjoint of the step epilogue (needs only saved quantities: runs next to the input fill)
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             const int q = w + qi * W;
             if (q < 4) {
                 const int d = 4 * q + g;
-                double fm = 0.0, fv = tile.sigma2;
-#pragma unroll
-                for (int ww = 0; ww < W; ++ww) {
-                    fm += part[ww * PSL + (0 * 4 + q) * 64 + l];
-                    fv += part[ww * PSL + (1 * 4 + q) * 64 + l];
-                }
                 double gfm = 0.0, gfv = 0.0;
                 if (act[qi] && cvalid) {
-                    const double fmean = fm + hcur[qi];
-                    const double fvar = fv + vx[qi];
+                    const double fmean = fmv_m[qi];        // saved by the forward evaluation (no recompute of P1/P2)
+                    const double fvar = fmv_v[qi];
                     const double gout = gcar[qi];
                     if (MODE == MODE_FWD) {
                         const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // cbfssm.py:227
@@ -437,7 +357,67 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 }
             }
         }
-        CBF_STAMP_BARRIER(3);
+        CBF_STAMP_BARRIER(0);
+
+        // ---- B: kernel tile (rows of this wave)
+        double bx[DK], xx = 0.0;
+#pragma unroll
+        for (int s = 0; s < DK; ++s) {
+            bx[s] = xq[(4 * s + g) * PD + nl];
+            xx = fma(bx[s], bx[s], xx);
+        }
+        xx += __shfl_xor(xx, 16);
+        xx += __shfl_xor(xx, 32);
+        d4 kreg[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            kreg[i] = d4{0, 0, 0, 0};
+            if (ok[i]) {
+                d4 e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = tile.czr[i][r] - 0.5 * xx;
+#pragma unroll
+                for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[i][s], bx[s], e);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    kreg[i][r] = exp(e[r]);
+                    Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
+                }
+            }
+        }
+        CBF_STAMP_BARRIER(1);
+
+        // ---- C: A2 rows of this wave, P1/P2
+        CBF_STAMP_MARK0();
+        d4 a2[RB];
+        {
+            d4 acc[RB][2];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
+            int s = 0;
+#pragma unroll 2
+            for (; s + 1 < KSr; s += 2) {
+                const double b0 = Kt[(4 * s + g) * PD + nl], b1 = Kt[(4 * s + 4 + g) * PD + nl];
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    if (ok[i]) {
+                        acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                        acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
+                    }
+                }
+            }
+            if (s < KSr) {
+                const double b0 = Kt[(4 * s + g) * PD + nl];
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) a2[i] = acc[i][0] + acc[i][1];
+        }
+        CBF_STAMP_MARK(0);
+        // (no P1/P2 here: fmean / fvar come from the forward evaluation; phase E follows without a barrier, it needs
+        //  only this wave's own A2 rows and the Fm/Fv tiles written two barriers ago)
 
         // ---- E: A2bar, and the parameter adjoints that contract over the 16 chains
         CBF_STAMP_MARK0();

@@ -101,6 +101,8 @@ struct PassArgs {
     int half;              // CBFSSMHALF forward pass (cbfssmhalf.py:117-172): x_0 from x0, Kalman update on d < dim_y only
     const double* x0;      // half: (B, dim_x) recognition-model output
     int group0, gtotal;    // this launch covers workgroup tiles [group0, group0 + gridDim.x) of gtotal (chain-group split)
+    double* fmv;           // optional: per-step (fmean, fvar) after residual / process noise, kept for the adjoint:
+                           // fwd [(T-1)][N][dim_x][2], bwd [2][T][N][dim_x-dim_y][2]
 };
 
 struct PredictArgs {
@@ -641,6 +643,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                 if (act[qi]) {
                     const double fmean = fm + hcur[qi];                                // cbfssm.py:145,205
                     const double fvar = fv + vx[qi];                                   // cbfssm.py:146,206
+                    if (a.fmv && cval[qi]) {
+                        const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                        double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
+                        o[0] = fmean; o[1] = fvar;
+                    }
                     if (MODE == MODE_FWD) {
                         const double vyt = vy[qi] + (a.k_factor - 1.0) * fvar;         // cbfssm.py:212-214
                         const double s = vyt + fvar;                                   // :216
@@ -868,6 +875,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
                 if (act[c][qi]) {
                     const double fmean = fm + hcur[c][qi];
                     const double fvar = fv + vx[c][qi];
+                    if (a.fmv && cval[c]) {
+                        const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                        double* o = a.fmv + ((slot * N + cch) * Do + d) * 2;
+                        o[0] = fmean; o[1] = fvar;
+                    }
                     if (MODE == MODE_FWD) {
                         const double vyt = vy[c][qi] + (a.k_factor - 1.0) * fvar;
                         const double sm = vyt + fvar;
