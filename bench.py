@@ -192,13 +192,14 @@ def main():
             lib.check(l.cbfssm_backward_pass_f64(C.byref(prob), C.byref(pack_b.layout), ops._ptr(pack_b.buf),
                                                  ops._ptr(var_x), ops._ptr(u), ops._ptr(y), ops._ptr(noise['hid_b']),
                                                  ops._ptr(noise['eps_b']), ops._ptr(ws.y2), ops._ptr(ws.h_all),
-                                                 ops._ptr(ws.fmv_b), ops._ptr(ws.ent_part), st), 'bwd')
+                                                 ops._ptr(ws.fmv_b), ops._ptr(ws.a2s_b), ops._ptr(ws.ent_part), st),
+                      'bwd')
 
         def k_fwd():
             lib.check(l.cbfssm_forward_pass_f64(C.byref(prob), C.byref(pack_f.layout), ops._ptr(pack_f.buf),
                                                 ops._ptr(var_x), ops._ptr(var_y), ops._ptr(u), ops._ptr(y),
                                                 ops._ptr(ws.y2), ops._ptr(noise['eps_f']), ops._ptr(ws.x),
-                                                ops._ptr(ws.fmv_f), ops._ptr(ws.kl_part), st), 'fwd')
+                                                ops._ptr(ws.fmv_f), ops._ptr(ws.a2s_f), ops._ptr(ws.kl_part), st), 'fwd')
 
         def F(M, D, Do):   # algorithmic FLOPs of one GP point evaluation
             return 2 * M * M + M * (2 * D + 5 * Do + 5)
@@ -213,17 +214,20 @@ def main():
                 lib.check(l.cbfssm_forward_pass_bwd_f64(C.byref(prob), C.byref(pack_f.layout), ops._ptr(pack_f.buf),
                                                         ops._ptr(var_x), ops._ptr(var_y), ops._ptr(u), ops._ptr(y),
                                                         ops._ptr(ws.y2), ops._ptr(noise['eps_f']), ops._ptr(ws.x),
-                                                        ops._ptr(ws.fmv_f), cL, ops._ptr(ws.gy2), ops._ptr(ws.gpart_f), st), 'rev fwd')
+                                                        ops._ptr(ws.fmv_f), ops._ptr(ws.a2s_f), cL, ops._ptr(ws.gy2), ops._ptr(ws.gpart_f), st), 'rev fwd')
 
             def k_rbwd():
                 lib.check(l.cbfssm_backward_pass_bwd_f64(C.byref(prob), C.byref(pack_b.layout), ops._ptr(pack_b.buf),
                                                          ops._ptr(var_x), ops._ptr(u), ops._ptr(y),
                                                          ops._ptr(noise['hid_b']), ops._ptr(noise['eps_b']),
-                                                         ops._ptr(ws.h_all), ops._ptr(ws.fmv_b), ops._ptr(ws.gy2), cE,
+                                                         ops._ptr(ws.h_all), ops._ptr(ws.fmv_b), ops._ptr(ws.a2s_b),
+                                                         ops._ptr(ws.gy2), cE,
                                                          ops._ptr(ws.gpart_b), st), 'rev bwd')
-            # adjoint of one GP evaluation: recompute (F) + reverse sweep (2F)  
-            kern['forward_pass_adjoint'] = (time_kernel(k_rfwd, 5), 3.0 * (w.T - 1) * N * F(w.M, w.D, w.dim_x))
-            kern['backward_pass_adjoint'] = (time_kernel(k_rbwd, 5), 6.0 * w.T * N * F(w.M, w.D, w.dim_out_b))
+            # adjoint of one GP evaluation: the reverse sweep costs 2F (K^-1 A2bar and the A2bar K^T outer product);
+            # without the saved A2 tiles the kernel also recomputes the evaluation itself (+F)  
+            fa = 2.0 if ws.a2s_b is not None else 3.0
+            kern['forward_pass_adjoint'] = (time_kernel(k_rfwd, 5), fa * (w.T - 1) * N * F(w.M, w.D, w.dim_x))
+            kern['backward_pass_adjoint'] = (time_kernel(k_rbwd, 5), fa * 2.0 * w.T * N * F(w.M, w.D, w.dim_out_b))
         name = max(kern, key=lambda k: kern[k][0])
         tk, fl = kern[name]
         ach = fl / tk / 1e12

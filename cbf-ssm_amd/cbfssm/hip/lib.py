@@ -20,6 +20,7 @@ SYMBOLS = (
     'cbfssm_elbo_combine_f64', 'cbfssm_rev_workgroups', 'cbfssm_forward_pass_bwd_f64',
     'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64', 'cbfssm_bwd_segments', 'cbfssm_forward_pass_bwd_ex_f64',
     'cbfssm_backward_pass_bwd_ex_f64', 'cbfssm_half_forward_pass_f64', 'cbfssm_half_forward_pass_bwd_f64',
+    'cbfssm_saved_a2_elems',
 )
 
 
@@ -65,21 +66,23 @@ def load():
     lib.cbfssm_gp_predict_f64.argtypes = [C.POINTER(PackLayout), vp, vp, i64, vp, vp, vp]
     lib.cbfssm_backward_pass_partials.restype = i64
     lib.cbfssm_backward_pass_partials.argtypes = [C.POINTER(Problem)]
-    lib.cbfssm_backward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 11
+    lib.cbfssm_backward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 12
     lib.cbfssm_forward_pass_partials.restype = i64
+    lib.cbfssm_saved_a2_elems.restype = i64
+    lib.cbfssm_saved_a2_elems.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout), ip]
     lib.cbfssm_forward_pass_partials.argtypes = [C.POINTER(Problem)]
-    lib.cbfssm_forward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 11
+    lib.cbfssm_forward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 12
     lib.cbfssm_loglik_moments_f64.argtypes = [C.POINTER(Problem)] + [vp] * 9
     lib.cbfssm_elbo_combine_f64.argtypes = [C.POINTER(Problem), dbl, dbl, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp]
     lib.cbfssm_rev_workgroups.restype = i64
     lib.cbfssm_rev_workgroups.argtypes = [C.POINTER(Problem), ip]
-    lib.cbfssm_forward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, vp, vp]
-    lib.cbfssm_backward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, vp]
+    lib.cbfssm_forward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10 + [dbl, vp, vp, vp]
+    lib.cbfssm_backward_pass_bwd_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10 + [dbl, vp, vp]
     lib.cbfssm_bwd_segments.argtypes = [C.POINTER(Problem)]
-    lib.cbfssm_forward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, vp, ip, ip, vp, vp, vp, i64, vp])
-    lib.cbfssm_backward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, ip, ip, ip, vp, vp, i64, vp])
-    lib.cbfssm_half_forward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 11
-    lib.cbfssm_half_forward_pass_bwd_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 8 + [dbl, vp, vp, ip, ip, vp, vp, vp, i64, vp])
+    lib.cbfssm_forward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10 + [dbl, vp, vp, ip, ip, vp, vp, vp, i64, vp])
+    lib.cbfssm_backward_pass_bwd_ex_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10 + [dbl, vp, ip, ip, ip, vp, vp, i64, vp])
+    lib.cbfssm_half_forward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 12
+    lib.cbfssm_half_forward_pass_bwd_f64.argtypes = ([C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, vp, ip, ip, vp, vp, vp, i64, vp])
     lib.cbfssm_reduce_partials_f64.argtypes = [vp, i64, i64, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)

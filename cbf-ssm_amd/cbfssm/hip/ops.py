@@ -4,6 +4,7 @@ All tensors are float64, contiguous, on one CUDA(=HIP) device.  Trajectories are
 (x: (T,N,dim_x), y2: (T,N,dim_x-dim_y), N = B*S, chain c = b*S + s); `as_btsd` gives the reference's (B,T,S,d) view.
 """
 import ctypes as C
+import os
 import torch
 
 from . import lib as _l
@@ -120,7 +121,7 @@ def as_btsd(x_tnd, B, S):
 class ElboWorkspace:
     """Device buffers of one ELBO evaluation for fixed (B, T) -- allocated once, reused every step."""
 
-    def __init__(self, prob, device, keep_h=False):
+    def __init__(self, prob, device, keep_h=False, packs=None):
         p = prob
         N, T = p.B * p.S, p.T
         dob = p.dim_x - p.dim_y
@@ -133,6 +134,15 @@ class ElboWorkspace:
         # every step's (fmean, fvar): the adjoint reads them instead of recomputing the predictive products
         self.fmv_b = torch.zeros(2, T, N, dob, 2, **f) if keep_h else None
         self.fmv_f = torch.zeros(max(T - 1, 0), N, p.dim_x, 2, **f) if keep_h else None
+        # every step's A2 = K^-1 k tiles: with them the adjoint skips one of its three M x M x 16 products per step.
+        # Kept only while both buffers fit CBFSSM_A2S_MAX_GB (default 24); otherwise the adjoint recomputes.
+        self.a2s_f = self.a2s_b = None
+        if keep_h and packs is not None:
+            n_f = int(lib.cbfssm_saved_a2_elems(C.byref(p), C.byref(packs[0].layout), 0))
+            n_b = int(lib.cbfssm_saved_a2_elems(C.byref(p), C.byref(packs[1].layout), 1)) if packs[1] is not None else 0
+            if 8.0 * (n_f + n_b) <= float(os.environ.get('CBFSSM_A2S_MAX_GB', '24')) * 2 ** 30:
+                self.a2s_f = torch.zeros(max(n_f, 1), **f)
+                self.a2s_b = torch.zeros(max(n_b, 1), **f) if packs[1] is not None else None
         self.x = torch.zeros(T, N, p.dim_x, **f)
         self.ent_part = torch.zeros(self.n_ent, **f)
         self.kl_part = torch.zeros(self.n_kl, **f)
@@ -162,11 +172,11 @@ def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, 
     assert eps_f.numel() == (prob.T - 1) * N
     rc = lib.cbfssm_backward_pass_f64(pb, C.byref(pack_b.layout), _ptr(pack_b.buf), _ptr(var_x), _ptr(u), _ptr(y),
                                       _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.fmv_b),
-                                      _ptr(ws.ent_part), st)
+                                      _ptr(ws.a2s_b), _ptr(ws.ent_part), st)
     _l.check(rc, 'cbfssm_backward_pass_f64')
     rc = lib.cbfssm_forward_pass_f64(pb, C.byref(pack_f.layout), _ptr(pack_f.buf), _ptr(var_x), _ptr(var_y),
                                      _ptr(u), _ptr(y), _ptr(ws.y2), _ptr(eps_f) if eps_f.numel() else None,
-                                     _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.kl_part), st)
+                                     _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st)
     _l.check(rc, 'cbfssm_forward_pass_f64')
     rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(var_y), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part), _ptr(ws.pred_mean),
                                        _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)

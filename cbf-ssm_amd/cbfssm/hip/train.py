@@ -114,7 +114,7 @@ class HipElboGrad:
     def _workspace(self, prob):
         key = (prob.B, prob.T)
         if key not in self._ws:
-            ws = ops.ElboWorkspace(prob, self.device, keep_h=True)
+            ws = ops.ElboWorkspace(prob, self.device, keep_h=True, packs=(self.pack_f, self.pack_b))
             lib = _l.load()
             n_f = int(lib.cbfssm_rev_workgroups(C.byref(prob), 0))
             n_b = int(lib.cbfssm_rev_workgroups(C.byref(prob), 1))
@@ -165,11 +165,12 @@ class HipElboGrad:
             rc = lib.cbfssm_forward_pass_bwd_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
                                                  _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
                                                  _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x),
-                                                 _ptr(ws.fmv_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), st)
+                                                 _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2),
+                                                 _ptr(ws.gpart_f), st)
             _l.check(rc, 'cbfssm_forward_pass_bwd_f64')
             rc = lib.cbfssm_backward_pass_bwd_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
                                                   _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
-                                                  _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.gy2), cE,
+                                                  _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.gy2), cE,
                                                   _ptr(ws.gpart_b), st)
             _l.check(rc, 'cbfssm_backward_pass_bwd_f64')
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
@@ -262,12 +263,13 @@ class HipElboGrad:
         def bwd(q, st):
             _l.check(lib.cbfssm_backward_pass_f64(C.byref(q), lb, _ptr(self.pack_b.buf), _ptr(c['var_x']), _ptr(u), _ptr(y),
                                                   _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all),
-                                                  _ptr(ws.fmv_b), _ptr(ws.ent_part), st), 'cbfssm_backward_pass_f64')
+                                                  _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.ent_part), st),
+                     'cbfssm_backward_pass_f64')
 
         def fwd(q, st):
             _l.check(lib.cbfssm_forward_pass_f64(C.byref(q), lf_, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
                                                  _ptr(u), _ptr(y), _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f),
-                                                 _ptr(ws.kl_part), st), 'cbfssm_forward_pass_f64')
+                                                 _ptr(ws.a2s_f), _ptr(ws.kl_part), st), 'cbfssm_forward_pass_f64')
         e0 = torch.cuda.Event()
         e0.record(s0)
         bwd(p_rest, st0)                       # the remainder groups first ...
@@ -299,12 +301,12 @@ class HipElboGrad:
         def rfwd(q, st):
             _l.check(lib.cbfssm_forward_pass_bwd_f64(C.byref(q), lf_, _ptr(self.pack_f.buf), _ptr(c['var_x']),
                                                      _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2), e_eps, _ptr(ws.x),
-                                                     _ptr(ws.fmv_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), st), 'cbfssm_forward_pass_bwd_f64')
+                                                     _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), st), 'cbfssm_forward_pass_bwd_f64')
 
         def rbwd(q, st):
             _l.check(lib.cbfssm_backward_pass_bwd_f64(C.byref(q), lb, _ptr(self.pack_b.buf), _ptr(c['var_x']), _ptr(u),
                                                       _ptr(y), _ptr(hid_b), _ptr(eps_b), _ptr(ws.h_all), _ptr(ws.fmv_b),
-                                                      _ptr(ws.gy2), cE, _ptr(ws.gpart_b), st),
+                                                      _ptr(ws.a2s_b), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), st),
                      'cbfssm_backward_pass_bwd_f64')
         rfwd(p_main, st0)                      # a whole number of rounds over the CUs
         e2 = torch.cuda.Event()
@@ -349,7 +351,8 @@ class HipElboGrad:
             rc = lib.cbfssm_forward_pass_bwd_ex_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
                                                     _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
                                                     _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x),
-                                                    _ptr(ws.fmv_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), t_hi, t_lo, _ptr(ws.gx_carry),
+                                                    _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f),
+                                                    t_hi, t_lo, _ptr(ws.gx_carry),
                                                     _ptr(sa), _ptr(sk), cols, st)
             _l.check(rc, 'cbfssm_forward_pass_bwd_ex_f64')
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp[:sf]), st), 'reduce f')
@@ -368,7 +371,8 @@ class HipElboGrad:
             cols = groups * 2 * (seg1 - seg0) * P * 16
             rc = lib.cbfssm_backward_pass_bwd_ex_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
                                                      _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
-                                                     _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.gy2), cE, _ptr(ws.gpart_b),
+                                                     _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.gy2), cE,
+                                                     _ptr(ws.gpart_b),
                                                      seg0, seg1, 1,
                                                      _ptr(sa), _ptr(sk), cols, st)
             _l.check(rc, 'cbfssm_backward_pass_bwd_ex_f64')

@@ -8,6 +8,7 @@ recog_len steps + a dense layer on B sequences (cbfssmhalf.py:82-93) -- a few hu
 PyTorch autograd (float64, TF-1.8 GRUCell gate layout) and receives d loss / d x_0 from the adjoint kernel.
 """
 import ctypes as C
+import os
 import math
 import torch
 
@@ -131,7 +132,7 @@ class HipHalfGrad:
         lay = C.byref(self.pack_f.layout)
         rc = lib.cbfssm_half_forward_pass_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
                                               _ptr(u), _ptr(y), _ptr(x0), _ptr(eps_f) if eps_f.numel() else None,
-                                              _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.kl_part), st)
+                                              _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st)
         _l.check(rc, 'cbfssm_half_forward_pass_f64')
         rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(c['var_y']), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part),
                                            _ptr(ws.pred_mean), _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)
@@ -165,6 +166,9 @@ class HipHalfGrad:
             ws.n_f = int(lib.cbfssm_rev_workgroups(C.byref(prob), 0))
             ws.x = torch.zeros(prob.T, N, prob.dim_x, **f)
             ws.fmv_f = torch.zeros(max(prob.T - 1, 0), N, prob.dim_x, 2, **f)
+            n_a2 = int(lib.cbfssm_saved_a2_elems(C.byref(prob), C.byref(self.pack_f.layout), 0))
+            keep = 8.0 * n_a2 <= float(os.environ.get('CBFSSM_A2S_MAX_GB', '24')) * 2 ** 30
+            ws.a2s_f = torch.zeros(max(n_a2, 1), **f) if keep else None
             ws.kl_part = torch.zeros(ws.n_kl, **f)
             ws.ll_part = torch.zeros(prob.B * prob.T * prob.dim_y, **f)
             ws.pred_mean = torch.zeros(prob.B, prob.T, prob.dim_y, **f)
@@ -241,7 +245,8 @@ class HipHalfGrad:
         if not self.stash:
             rc = lib.cbfssm_half_forward_pass_bwd_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
                                                       _ptr(u), _ptr(y), _ptr(eps_f) if eps_f.numel() else None,
-                                                      _ptr(ws.x), _ptr(ws.fmv_f), cL, _ptr(ws.gx0), _ptr(ws.gpart_f),
+                                                      _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0),
+                                                      _ptr(ws.gpart_f),
                                                       T - 2, 0, None,
                                                       None, None, 0, st)
             _l.check(rc, 'cbfssm_half_forward_pass_bwd_f64')
@@ -264,7 +269,7 @@ class HipHalfGrad:
                 rc = lib.cbfssm_half_forward_pass_bwd_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']),
                                                           _ptr(c['var_y']), _ptr(u), _ptr(y),
                                                           _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x),
-                                                          _ptr(ws.fmv_f), cL, _ptr(ws.gx0), _ptr(ws.gpart_f), t_hi, t_lo, _ptr(ws.gx_carry),
+                                                          _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0), _ptr(ws.gpart_f), t_hi, t_lo, _ptr(ws.gx_carry),
                                                           _ptr(sa), _ptr(sk), cols, st)
                 _l.check(rc, 'cbfssm_half_forward_pass_bwd_f64')
                 _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp), st), 'reduce f')

@@ -61,6 +61,8 @@ struct RevArgs {
     int half;              // CBFSSMHALF forward pass
     double* gx0;           // half: (N, dim_x) d loss / d x_0 per chain (summed over the particles by the caller)
     int group0, gtotal;    // this launch covers chain groups [group0, group0 + gridDim.x) of gtotal
+    const double* a2s;     // optional: A2 = K^-1 k tiles of every step as saved by the forward evaluation
+                           // (PassArgs::a2s layout); NULL -> phase C recomputes them
     const double* fmv;     // (fmean, fvar) of every step as saved by the forward evaluation (PassArgs::fmv layout)
 };
 
@@ -288,6 +290,20 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 fmv_m[qi] = o[0]; fmv_v[qi] = o[1];
             }
         }
+        // A2 rows of this wave, if the forward evaluation kept them (consumed after the second barrier)
+        d4 a2[RB];
+        if (a.a2s) {
+            const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+            const double* ap = a.a2s + (slot * ((N + 15) >> 4) + (c0 >> 4)) * (NBLK * 256) + l;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                a2[i] = d4{0, 0, 0, 0};
+                if (ok[i]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a2[i][r] = ap[rbs[i] * 256 + r * 64];
+                }
+            }
+        }
         // ---- D: adjoint of the step epilogue (needs only saved quantities: runs next to the input fill)
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
@@ -389,8 +405,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
 
         // ---- C: A2 rows of this wave, P1/P2
         CBF_STAMP_MARK0();
-        d4 a2[RB];
-        {
+        if (!a.a2s) {
             d4 acc[RB][2];
 #pragma unroll
             for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }

@@ -592,8 +592,8 @@ int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p)
 
 int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_b,
                              const double* var_x, const double* u, const double* y, const double* hid_b,
-                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* ent_part,
-                             void* stream)
+                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* a2s_b,
+                             double* ent_part, void* stream)
 {
     int rc = check_problem(p, L, p ? p->dim_x - p->dim_y : 0);
     if (rc) return rc;
@@ -609,6 +609,7 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.part_out = ent_part;
     a.dbg = g_dbg;
     a.fmv = fmv_b;
+    a.a2s = a2s_b;
     int n0, n1;
     bwd_segments(p, &n0, &n1);
     a.nseg0 = n0;
@@ -623,6 +624,14 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
     return 0;
 }
 
+int64_t cbfssm_saved_a2_elems(const cbfssm_problem* p, const cbfssm_pack_layout* L, int backward)
+{
+    if (!p || !L) return -1;
+    const int64_t g16 = (int64_t(p->B) * p->S + 15) / 16;
+    const int64_t slots = backward ? 2 * int64_t(p->T) : (p->T > 1 ? p->T - 1 : 0);
+    return slots * g16 * L->NBLK * 256;
+}
+
 int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p)
 {
     if (!p) return -1;
@@ -632,7 +641,7 @@ int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p)
 static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
                              const double* var_x, const double* var_y, const double* u, const double* y,
                              const double* y2, const double* x0, const double* eps_f, double* x, double* fmv_f,
-                             double* kl_part, void* stream)
+                             double* a2s_f, double* kl_part, void* stream)
 {
     int rc = check_problem(p, L, p ? p->dim_x : 0);
     if (rc) return rc;
@@ -650,6 +659,7 @@ static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.dbg = g_dbg;
     a.half = p->half; a.x0 = x0;
     a.fmv = fmv_f;
+    a.a2s = a2s_f;
     const int nc = pass_nc(p, MODE_FWD);
     int g0, ng, gt;
     rc = group_range(p, nc, &g0, &ng, &gt);
@@ -663,20 +673,20 @@ static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* 
 
 int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
-                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* kl_part,
-                            void* stream)
+                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* a2s_f,
+                            double* kl_part, void* stream)
 {
     if (p && p->half) return fail(-1, "problem->half is set: use cbfssm_half_forward_pass_f64");
-    return forward_pass_impl(p, L, pack_f, var_x, var_y, u, y, y2, nullptr, eps_f, x, fmv_f, kl_part, stream);
+    return forward_pass_impl(p, L, pack_f, var_x, var_y, u, y, y2, nullptr, eps_f, x, fmv_f, a2s_f, kl_part, stream);
 }
 
 int cbfssm_half_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
                                  const double* var_x, const double* var_y, const double* u, const double* y,
-                                 const double* x0, const double* eps_f, double* x, double* fmv_f, double* kl_part,
-                                 void* stream)
+                                 const double* x0, const double* eps_f, double* x, double* fmv_f, double* a2s_f,
+                                 double* kl_part, void* stream)
 {
     if (!p || !p->half) return fail(-1, "problem->half must be 1");
-    return forward_pass_impl(p, L, pack_f, var_x, var_y, u, y, nullptr, x0, eps_f, x, fmv_f, kl_part, stream);
+    return forward_pass_impl(p, L, pack_f, var_x, var_y, u, y, nullptr, x0, eps_f, x, fmv_f, a2s_f, kl_part, stream);
 }
 
 int cbfssm_loglik_moments_f64(const cbfssm_problem* p, const double* var_y, const double* y, const double* x,
@@ -767,8 +777,8 @@ static int set_stash(RevArgs& a, const cbfssm_pack_layout* L, double* stash_a, d
 
 static int forward_pass_bwd_impl(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
                                  const double* var_x, const double* var_y, const double* u, const double* y,
-                                 const double* y2, const double* eps_f, const double* x, const double* fmv_f, double cL,
-                                 double* gy2,
+                                 const double* y2, const double* eps_f, const double* x, const double* fmv_f,
+                                 const double* a2s_f, double cL, double* gy2,
                                  double* gx0, double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
                                  double* stash_k, int64_t stash_ld, void* stream)
 {
@@ -787,6 +797,7 @@ static int forward_pass_bwd_impl(const cbfssm_problem* p, const cbfssm_pack_layo
     a.gpart = gpart; a.t_hi = t_hi; a.t_lo = t_lo; a.gx_carry = gx_carry;
     a.half = p->half; a.gx0 = gx0;
     a.fmv = fmv_f;
+    a.a2s = a2s_f;
     const int64_t groups = (a.N + 15) / 16;
     const int steps = t_hi >= t_lo ? t_hi - t_lo + 1 : 0;
     rc = set_stash(a, L, stash_a, stash_k, stash_ld, groups, steps);
@@ -804,39 +815,39 @@ static int forward_pass_bwd_impl(const cbfssm_problem* p, const cbfssm_pack_layo
 int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
                                    const double* var_x, const double* var_y, const double* u, const double* y,
                                    const double* y2, const double* eps_f, const double* x, const double* fmv_f,
-                                   double cL, double* gy2, double* gpart, int t_hi, int t_lo, double* gx_carry,
-                                   double* stash_a, double* stash_k, int64_t stash_ld, void* stream)
+                                   const double* a2s_f, double cL, double* gy2, double* gpart, int t_hi, int t_lo,
+                                   double* gx_carry, double* stash_a, double* stash_k, int64_t stash_ld, void* stream)
 {
     if (p && p->half) return fail(-1, "problem->half is set: use cbfssm_half_forward_pass_bwd_f64");
-    return forward_pass_bwd_impl(p, L, pack_f, var_x, var_y, u, y, y2, eps_f, x, fmv_f, cL, gy2, nullptr, gpart, t_hi,
-                                 t_lo, gx_carry, stash_a, stash_k, stash_ld, stream);
+    return forward_pass_bwd_impl(p, L, pack_f, var_x, var_y, u, y, y2, eps_f, x, fmv_f, a2s_f, cL, gy2, nullptr, gpart,
+                                 t_hi, t_lo, gx_carry, stash_a, stash_k, stash_ld, stream);
 }
 
 int cbfssm_half_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
                                      const double* var_x, const double* var_y, const double* u, const double* y,
-                                     const double* eps_f, const double* x, const double* fmv_f, double cL, double* gx0,
-                                     double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
+                                     const double* eps_f, const double* x, const double* fmv_f, const double* a2s_f, double cL,
+                                     double* gx0, double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
                                      double* stash_k, int64_t stash_ld, void* stream)
 {
     if (!p || !p->half) return fail(-1, "problem->half must be 1");
-    return forward_pass_bwd_impl(p, L, pack_f, var_x, var_y, u, y, nullptr, eps_f, x, fmv_f, cL, nullptr, gx0, gpart,
+    return forward_pass_bwd_impl(p, L, pack_f, var_x, var_y, u, y, nullptr, eps_f, x, fmv_f, a2s_f, cL, nullptr, gx0, gpart,
                                  t_hi, t_lo, gx_carry, stash_a, stash_k, stash_ld, stream);
 }
 
 int cbfssm_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_f,
                                 const double* var_x, const double* var_y, const double* u, const double* y,
-                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, double cL,
-                                double* gy2, double* gpart, void* stream)
+                                const double* y2, const double* eps_f, const double* x, const double* fmv_f,
+                                const double* a2s_f, double cL, double* gy2, double* gpart, void* stream)
 {
     if (L && L->rev_stash) return fail(-3, "M=%d runs in stash mode: use cbfssm_forward_pass_bwd_ex_f64", L->M);
-    return cbfssm_forward_pass_bwd_ex_f64(p, L, pack_f, var_x, var_y, u, y, y2, eps_f, x, fmv_f, cL, gy2, gpart,
+    return cbfssm_forward_pass_bwd_ex_f64(p, L, pack_f, var_x, var_y, u, y, y2, eps_f, x, fmv_f, a2s_f, cL, gy2, gpart,
                                           p ? p->T - 2 : -1, 0, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_b,
                                     const double* var_x, const double* u, const double* y, const double* hid_b,
-                                    const double* eps_b, const double* h_all, const double* fmv_b, const double* gy2,
-                                    double cE, double* gpart, int seg0, int seg1, int nchunk, double* stash_a,
+                                    const double* eps_b, const double* h_all, const double* fmv_b, const double* a2s_b,
+                                    const double* gy2, double cE, double* gpart, int seg0, int seg1, int nchunk, double* stash_a,
                                     double* stash_k, int64_t stash_ld, void* stream)
 {
     int rc = check_problem(p, L, p ? p->dim_x - p->dim_y : 0);
@@ -851,6 +862,7 @@ int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_l
     a.cE = cE; a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.h_all = h_all;
     a.gy2 = const_cast<double*>(gy2); a.gpart = gpart;
     a.fmv = fmv_b;
+    a.a2s = a2s_b;
     a.seg0 = seg0; a.seg1 = seg1; a.nchunk = nchunk;
     const int64_t groups = (a.N + 15) / 16;
     const int per = (seg1 - seg0 + nchunk - 1) / nchunk;
@@ -868,12 +880,12 @@ int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_l
 
 int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_b,
                                  const double* var_x, const double* u, const double* y, const double* hid_b,
-                                 const double* eps_b, const double* h_all, const double* fmv_b, const double* gy2,
-                                 double cE, double* gpart, void* stream)
+                                 const double* eps_b, const double* h_all, const double* fmv_b, const double* a2s_b,
+                                 const double* gy2, double cE, double* gpart, void* stream)
 {
     if (L && L->rev_stash) return fail(-3, "M=%d runs in stash mode: use cbfssm_backward_pass_bwd_ex_f64", L->M);
     if (!p || p->recog_len < 1) return fail(-1, "null problem");
-    return cbfssm_backward_pass_bwd_ex_f64(p, L, pack_b, var_x, u, y, hid_b, eps_b, h_all, fmv_b, gy2, cE, gpart, 0,
+    return cbfssm_backward_pass_bwd_ex_f64(p, L, pack_b, var_x, u, y, hid_b, eps_b, h_all, fmv_b, a2s_b, gy2, cE, gpart, 0,
                                            bwd_total_segments(p), rev_chunks(p), nullptr, nullptr, 0, stream);
 }
 

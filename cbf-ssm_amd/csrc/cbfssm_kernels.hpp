@@ -101,6 +101,8 @@ struct PassArgs {
     int half;              // CBFSSMHALF forward pass (cbfssmhalf.py:117-172): x_0 from x0, Kalman update on d < dim_y only
     const double* x0;      // half: (B, dim_x) recognition-model output
     int group0, gtotal;    // this launch covers workgroup tiles [group0, group0 + gridDim.x) of gtotal (chain-group split)
+    double* a2s;           // optional: per-step A2 = K^-1 k tiles kept for the adjoint, [slot][16-chain group][NBLK*256]
+                           // in MFMA C-layout (slot = t for fwd, run*T + t for bwd)
     double* fmv;           // optional: per-step (fmean, fvar) after residual / process noise, kept for the adjoint:
                            // fwd [(T-1)][N][dim_x][2], bwd [2][T][N][dim_x-dim_y][2]
 };
@@ -171,7 +173,8 @@ struct Tile {
     // of this wave in part[c].  Contains one workgroup barrier; the caller must barrier before reading `part` and
     // before rewriting xq.  With NC = 2 every K^-1 operand feeds two MFMAs (two independent accumulator chains).
     template <int NC>
-    __device__ __forceinline__ void gp_phases(const double* xq, double* Kt, double* part, int w, int l)
+    __device__ __forceinline__ void gp_phases(const double* xq, double* Kt, double* part, int w, int l,
+                                              double* a2o = nullptr, int ncol_ok = NC)
     {
         constexpr int XS = DK * 64, KTS = MP * 16, PS = W * 512;
         // ---- phase 1: kernel tile rows of this wave
@@ -270,6 +273,10 @@ struct Tile {
                 const int rb = w * RB + i;
                 if (rb < NBLK) {
                     const d4 a2 = acc[c][i][0] + acc[c][i][1];
+                    if (a2o && c < ncol_ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a2o[(c * NBLK + rb) * 256 + r * 64 + l] = a2[r];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const double mu_op = BREG ? muA[i][r] : muAg[(rb * 4 + r) * 64 + lane_];
@@ -323,7 +330,8 @@ struct Tile {
         }
     }
 
-    __device__ __forceinline__ void phase2(const double* Kt, double* part, const double (&kreg)[RB][4], int w, int l)
+    __device__ __forceinline__ void phase2(const double* Kt, double* part, const double (&kreg)[RB][4], int w, int l,
+                                           double* a2o = nullptr)
     {
         d4 acc[RB][2];
 #pragma unroll
@@ -360,6 +368,10 @@ struct Tile {
             const int rb = w * RB + i;
             if (rb < NBLK) {
                 const d4 a2 = acc[i][0] + acc[i][1];
+                if (a2o) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a2o[rb * 256 + r * 64 + l] = a2[r];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double mu_op = BREG ? muA[i][r] : muAg[(rb * 4 + r) * 64 + lane_];
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     const int naux = a.D - Do;                       // rows of the GP input that are not chain state
     const int gx = blockIdx.x + a.group0;            // chain group of this workgroup
     const int c0 = gx * 16 * NC;
+    const int G16 = (N + 15) >> 4;
 
     // ---- time range of this workgroup
     int t_first, nsteps, dir, run = 0;
@@ -620,13 +633,18 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                 auxr[cb][k2] = (has_next && i < 16 * naux) ? aux_load(cb, i, tn) : 0.0;
             }
 
+        double* a2o = nullptr;                        // this step's A2 tiles, kept for the adjoint
+        if (a.a2s) {
+            const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+            a2o = a.a2s + (slot * G16 + int64_t(gx) * NC) * (NBLK * 256);
+        }
         if constexpr (NC == 1) {
             double kr[RB][4];
             tile.phase1(xq, Kt, kr, w, l);
             CBF_STAMP_BARRIER(1);
-            tile.phase2(Kt, part, kr, w, l);
+            tile.phase2(Kt, part, kr, w, l, a2o);
         } else {
-            tile.template gp_phases<NC>(xq, Kt, part, w, l);
+            tile.template gp_phases<NC>(xq, Kt, part, w, l, a2o, G16 - gx * NC);
         }
         CBF_STAMP_BARRIER(2);                         // part complete; xq and Kt free
 
@@ -926,6 +944,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
+    const int G16 = (N + 15) >> 4;
+    auto a2slot = [&](int s, int c) -> double* {      // A2 tiles of step s, column block c (kept for the adjoint)
+        if (!a.a2s || 2 * gx + c >= G16) return nullptr;
+        const int t = t_first + dir * s;
+        const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+        return a.a2s + (slot * G16 + 2 * gx + c) * (NBLK * 256);
+    };
     tile.phase1(xq, Kt, kregA, w, l);                                   // phase1(A, 0)
     __syncthreads();
     // SIMD partners (waves w and w+4) run the two halves of an interval in opposite order, so that one is in its
@@ -935,9 +960,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
         // alpha: phase2(A, s) || phase3(B, s-1)   (B's epilogue lanes sit on the high waves)
         if (hi) {
             if (s > 0) phase3(I1{}, s - 1);
-            tile.phase2(Kt, part, kregA, w, l);
+            tile.phase2(Kt, part, kregA, w, l, a2slot(s, 0));
         } else {
-            tile.phase2(Kt, part, kregA, w, l);
+            tile.phase2(Kt, part, kregA, w, l, a2slot(s, 0));
             if (s > 0) phase3(I1{}, s - 1);
         }
         __syncthreads();
@@ -952,11 +977,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
         __syncthreads();
         // gamma: phase2(B, s) || phase1(A, s+1)
         if (hi) {
-            tile.phase2(Kt + KTS, part + PS, kregB, w, l);
+            tile.phase2(Kt + KTS, part + PS, kregB, w, l, a2slot(s, 1));
             if (s + 1 < nsteps) tile.phase1(xq, Kt, kregA, w, l);
         } else {
             if (s + 1 < nsteps) tile.phase1(xq, Kt, kregA, w, l);
-            tile.phase2(Kt + KTS, part + PS, kregB, w, l);
+            tile.phase2(Kt + KTS, part + PS, kregB, w, l, a2slot(s, 1));
         }
         __syncthreads();
     }

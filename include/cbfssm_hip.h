@@ -120,6 +120,8 @@ int cbfssm_gp_predict_f64(const cbfssm_pack_layout* layout, const double* pack, 
  *      h_all (2,T,N,dim_x-dim_y) or NULL: every step's output of both runs (kept for the adjoint)
  *      fmv_b (2,T,N,dim_x-dim_y,2) or NULL: every step's (fmean, fvar) after residual and process noise (kept for
  *      the adjoint, which then needs no recomputation of the predictive products)
+ *      a2s_b (cbfssm_saved_a2_elems(p, L, 1) doubles) or NULL: every step's A2 = K_mm^-1 K_mn tiles, kept for the
+ *      adjoint (which otherwise recomputes them: one M x M x 16 product per step less)
  *      ent_part (n_ent_part doubles): per-workgroup partial sums of 0.5*sum(log(2 pi e) + log fvar) over the
  *      written steps (cbfssm.py:154-156); their sum is `entropy` (cbfssm.py:99).
  *   cbfssm_backward_pass_partials(problem) gives n_ent_part.
@@ -127,21 +129,27 @@ int cbfssm_gp_predict_f64(const cbfssm_pack_layout* layout, const double* pack, 
 int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p);
 int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const double* pack_b,
                              const double* var_x, const double* u, const double* y, const double* hid_b,
-                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* ent_part,
-                             void* stream);
+                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* a2s_b,
+                             double* ent_part, void* stream);
 
 /*
  * Forward (filter) pass, CBFSSM._forward/_forward_body (cbfssm.py:160-237).
  *   y2 (T,N,dim_x-dim_y) from the backward pass, eps_f (T-1,N), var_x (dim_x), var_y (dim_x)
  *   -> x (T,N,dim_x)   [x[0] = y_tilde[0], cbfssm.py:168]
  *      fmv_f (T-1,N,dim_x,2) or NULL: every step's (fmean, fvar), kept for the adjoint
+ *      a2s_f (cbfssm_saved_a2_elems(p, L, 0) doubles) or NULL: every step's A2 tiles, kept for the adjoint
  *      kl_part (n_kl_part doubles): per-workgroup partial sums of kl_reg (cbfssm.py:232-235); sum = kl_x.
  */
 int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p);
+
+/* Doubles in the optional saved-A2 buffer of the backward (backward != 0) or forward pass: one M_pad x 16 tile per
+ * step and 16-chain group, T*2 resp. T-1 steps (no reference counterpart: TF keeps its forward activations for
+ * tf.gradients the same way, base_model.py:34-36). */
+int64_t cbfssm_saved_a2_elems(const cbfssm_problem* p, const cbfssm_pack_layout* layout, int backward);
 int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
-                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* kl_part,
-                            void* stream);
+                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* a2s_f,
+                            double* kl_part, void* stream);
 
 /*
  * CBFSSMHALF (cbfssm/model/cbfssmhalf.py:97-172): the forward pass with x_0 = recognition-model output x0 (B,dim_x),
@@ -151,12 +159,12 @@ int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* l
  */
 int cbfssm_half_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
                                  const double* var_x, const double* var_y, const double* u, const double* y,
-                                 const double* x0, const double* eps_f, double* x, double* fmv_f, double* kl_part,
-                                 void* stream);
+                                 const double* x0, const double* eps_f, double* x, double* fmv_f, double* a2s_f,
+                                 double* kl_part, void* stream);
 int cbfssm_half_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
                                      const double* var_x, const double* var_y, const double* u, const double* y,
-                                     const double* eps_f, const double* x, const double* fmv_f, double cL, double* gx0,
-                                     double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
+                                     const double* eps_f, const double* x, const double* fmv_f, const double* a2s_f, double cL,
+                                     double* gx0, double* gpart, int t_hi, int t_lo, double* gx_carry, double* stash_a,
                                      double* stash_k, int64_t stash_ld, void* stream);
 
 /*
@@ -197,23 +205,23 @@ int64_t cbfssm_rev_workgroups(const cbfssm_problem* p, int backward_runs);
 /*
  * Adjoint of cbfssm_forward_pass_f64 (reverse of the tf.while_loop in CBFSSM._forward, cbfssm.py:176-237) including
  * the log-likelihood's pull on x (cbfssm.py:245-251).
- *   x, y2, eps_f, fmv_f as saved by the forward evaluation; cL = loss_factors[0]/S.
+ *   x, y2, eps_f, fmv_f (and a2s_f, or NULL to recompute A2) as saved by the forward evaluation; cL = loss_factors[0]/S.
  *   -> gy2 (T,N,dim_x-dim_y): d loss / d y2 ; gpart: cbfssm_rev_workgroups(p,0) slabs of layout_f->rev_slab doubles.
  */
 int cbfssm_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
                                 const double* var_x, const double* var_y, const double* u, const double* y,
-                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, double cL,
-                                double* gy2, double* gpart, void* stream);
+                                const double* y2, const double* eps_f, const double* x, const double* fmv_f,
+                                const double* a2s_f, double cL, double* gy2, double* gpart, void* stream);
 
 /*
  * Adjoint of cbfssm_backward_pass_f64 (both runs; reverse of the tf.while_loops in CBFSSM._backward_run,
- * cbfssm.py:107-158).  h_all, fmv_b as saved by the forward evaluation, gy2 from cbfssm_forward_pass_bwd_f64,
+ * cbfssm.py:107-158).  h_all, fmv_b (and a2s_b, or NULL) as saved by the forward evaluation, gy2 from cbfssm_forward_pass_bwd_f64,
  * cE = loss_factors[1]/S.  -> gpart: cbfssm_rev_workgroups(p,1) slabs of layout_b->rev_slab doubles.
  */
 int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const double* pack_b,
                                  const double* var_x, const double* u, const double* y, const double* hid_b,
-                                 const double* eps_b, const double* h_all, const double* fmv_b, const double* gy2,
-                                 double cE, double* gpart, void* stream);
+                                 const double* eps_b, const double* h_all, const double* fmv_b, const double* a2s_b,
+                                 const double* gy2, double cE, double* gpart, void* stream);
 
 /*
  * General forms of the two adjoint passes: a time range per launch, and "stash mode" for tile heights whose
@@ -232,13 +240,13 @@ int cbfssm_bwd_segments(const cbfssm_problem* p);
 int cbfssm_forward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
                                    const double* var_x, const double* var_y, const double* u, const double* y,
                                    const double* y2, const double* eps_f, const double* x, const double* fmv_f,
-                                   double cL, double* gy2, double* gpart, int t_hi, int t_lo, double* gx_carry,
-                                   double* stash_a, double* stash_k, int64_t stash_ld, void* stream);
+                                   const double* a2s_f, double cL, double* gy2, double* gpart, int t_hi, int t_lo,
+                                   double* gx_carry, double* stash_a, double* stash_k, int64_t stash_ld, void* stream);
 int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const double* pack_b,
                                     const double* var_x, const double* u, const double* y, const double* hid_b,
-                                    const double* eps_b, const double* h_all, const double* fmv_b, const double* gy2,
-                                    double cE, double* gpart, int seg0, int seg1, int nchunk, double* stash_a,
-                                    double* stash_k, int64_t stash_ld, void* stream);
+                                    const double* eps_b, const double* h_all, const double* fmv_b, const double* a2s_b,
+                                    const double* gy2, double cE, double* gpart, int seg0, int seg1, int nchunk,
+                                    double* stash_a, double* stash_k, int64_t stash_ld, void* stream);
 
 /* out[i] = sum over the nwg slabs, in a fixed order (bitwise reproducible).  gpart must have room for
  * nwg + CBFSSM_REDUCE_SPLIT slabs: the tail is scratch for the first of the two reduction stages. */

@@ -32,11 +32,11 @@ for tag in ('bwd', 'fwd'):
         if tag == 'bwd':
             lib.check(l.cbfssm_backward_pass_f64(C.byref(prob), C.byref(eng.pack_b.layout), ops._ptr(eng.pack_b.buf),
                       ops._ptr(eng.var_x), ops._ptr(u), ops._ptr(y), ops._ptr(noise['hid_b']), ops._ptr(noise['eps_b']),
-                      ops._ptr(ws.y2), None, None, ops._ptr(ws.ent_part), st), 'bwd')
+                      ops._ptr(ws.y2), None, None, None, ops._ptr(ws.ent_part), st), 'bwd')
         else:
             lib.check(l.cbfssm_forward_pass_f64(C.byref(prob), C.byref(eng.pack_f.layout), ops._ptr(eng.pack_f.buf),
                       ops._ptr(eng.var_x), ops._ptr(eng.var_y), ops._ptr(u), ops._ptr(y), ops._ptr(ws.y2),
-                      ops._ptr(noise['eps_f']), ops._ptr(ws.x), None, ops._ptr(ws.kl_part), st), 'fwd')
+                      ops._ptr(noise['eps_f']), ops._ptr(ws.x), None, None, ops._ptr(ws.kl_part), st), 'fwd')
     torch.cuda.synchronize()
     d = dbg.view(-1, 64).cpu().numpy()
     d = d[d.sum(1) > 0]
