@@ -94,8 +94,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     typedef Slab<NBLK, JB, STASH> SL;
 
     extern __shared__ double lds[];
-    double* xq = lds;                                   // [4*DK][17]
-    double* Kt = xq + 4 * DK * PD;                      // [MP][17]
+    double* xq0 = lds;                                  // [2][4*DK][17]: this step's and the next step's inputs
+    double* Kt = xq0 + 2 * 4 * DK * PD;                 // [MP][17]
     double* A2t = Kt + MP * PD;                         // [MP][17]
     double* Fm = A2t + MP * PD;                         // [16][17]
     double* Fv = Fm + 16 * PD;                          // [16][17]
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         return v * a.pk.invl[Do + ja];
     };
 
-    for (int i = tid; i < 4 * DK * PD; i += NT) xq[i] = 0.0;
+    for (int i = tid; i < 2 * 4 * DK * PD; i += NT) xq0[i] = 0.0;
+    double* xq = xq0;
     for (int i = tid; i < 16 * PD; i += NT) { Fm[i] = 0.0; Fv[i] = 0.0; }
     if (BLDS) {
 #pragma unroll
@@ -226,70 +227,178 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         }
     }
 
-    CBF_STAMP_DECL;
-    CBF_STAMP_START();
-#ifdef CBF_REV_STAMPS
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    for (int step = 0; step < nsteps; ++step) {
-        const int t = (MODE == MODE_FWD) ? (a.t_hi - step) : (t_begin + step);
-
-        // ---- A: GP input of step t from the saved trajectory
-        double hcur[QPW];
-        bool resample_t = false;
-        if (MODE == MODE_BWD) resample_t = (((t + 1 + run * R) % P) == 0);                    // cbfssm.py:124,127
+    // ---- step pipeline.  The GP input of step s+1 (saved trajectory, no dependence on the reverse sweep) is loaded
+    // while step s computes and lands in the other xq buffer; the epilogue adjoint of step s+1 (phase D) follows phase
+    // G of step s in the same lanes, so a step has four workgroup barriers and no load latency on its critical path.
+    auto t_of = [&](int step) -> int { return (MODE == MODE_FWD) ? (a.t_hi - step) : (t_begin + step); };
+    auto load_inputs = [&](int t, double (&hv)[QPW], double (&av)[AUXR]) {
+        bool rs = false;
+        if (MODE == MODE_BWD) rs = (((t + 1 + run * R) % P) == 0);                            // cbfssm.py:124,127
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
-            const int q = w + qi * W;
-            const int d = 4 * q + g;
-            hcur[qi] = 0.0;
+            const int d = 4 * (w + qi * W) + g;
+            hv[qi] = 0.0;
             if (act[qi]) {
                 double v;
                 if (MODE == MODE_FWD) v = a.x[(int64_t(t) * N + c) * a.dim_x + d];
-                else if (resample_t) v = a.hid[(int64_t(run) * T + t) * N + c];
+                else if (rs) v = a.hid[(int64_t(run) * T + t) * N + c];
                 else if (t == T - 1) v = 0.0;                                                  // cbfssm.py:106
                 else v = a.h_all[((int64_t(run) * T + (t + 1)) * N + c) * Do + d];             // h_t = out_{t+1}
-                hcur[qi] = v;
-                xq[d * PD + nl] = v * il[qi];
+                hv[qi] = v;
             }
         }
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT;
-            if (i < 16 * naux) xq[(Do + (i >> 4)) * PD + (i & 15)] = aux_load(i, t);
+            av[k2] = (i < 16 * naux) ? aux_load(i, t) : 0.0;
         }
-        // epilogue inputs
-        double eps_t, ytil[QPW], gy2in[QPW];
-        if (MODE == MODE_FWD) {
-            eps_t = a.eps[int64_t(t) * N + c];
-#pragma unroll
-            for (int qi = 0; qi < QPW; ++qi) {
-                const int d = 4 * (w + qi * W) + g;
-                ytil[qi] = 0.0;
-                if (act[qi]) {
-                    if (d < a.dim_y) ytil[qi] = a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d];
-                    else if (!a.half) ytil[qi] = a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)];
-                }
-            }
-        } else {
-            eps_t = a.eps[(int64_t(run) * T + t) * N + c];
-#pragma unroll
-            for (int qi = 0; qi < QPW; ++qi) {
-                const int d = 4 * (w + qi * W) + g;
-                gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
-            }
-        }
-        double fmv_m[QPW], fmv_v[QPW];
+    };
+    auto store_inputs = [&](double* xb, const double (&hv)[QPW], const double (&av)[AUXR]) {
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             const int d = 4 * (w + qi * W) + g;
-            fmv_m[qi] = 0.0; fmv_v[qi] = 1.0;
-            if (act[qi]) {
-                const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
-                const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
-                fmv_m[qi] = o[0]; fmv_v[qi] = o[1];
-            }
+            if (act[qi]) xb[d * PD + nl] = hv[qi] * il[qi];
         }
+#pragma unroll
+        for (int k2 = 0; k2 < AUXR; ++k2) {
+            const int i = tid + k2 * NT;
+            if (i < 16 * naux) xb[(Do + (i >> 4)) * PD + (i & 15)] = av[k2];
+        }
+    };
+    // phase D of step t: adjoint of the step epilogue from the carried state adjoint -> Fm, Fv tiles, gdir
+    // inputs of phase D of step t: {eps, y~ (fwd) or the y2 adjoint (bwd), fmean, fvar}
+    auto epilogue_load = [&](int t, double& eps_t, double (&ytil)[QPW], double (&fmv_m)[QPW], double (&fmv_v)[QPW]) {
+            double (&gy2in)[QPW] = ytil;
+            if (MODE == MODE_FWD) {
+                eps_t = a.eps[int64_t(t) * N + c];
+#pragma unroll
+                for (int qi = 0; qi < QPW; ++qi) {
+                    const int d = 4 * (w + qi * W) + g;
+                    ytil[qi] = 0.0;
+                    if (act[qi]) {
+                        if (d < a.dim_y) ytil[qi] = a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d];
+                        else if (!a.half) ytil[qi] = a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)];
+                    }
+                }
+            } else {
+                eps_t = a.eps[(int64_t(run) * T + t) * N + c];
+#pragma unroll
+                for (int qi = 0; qi < QPW; ++qi) {
+                    const int d = 4 * (w + qi * W) + g;
+                    gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int d = 4 * (w + qi * W) + g;
+                fmv_m[qi] = 0.0; fmv_v[qi] = 1.0;
+                if (act[qi]) {
+                    const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                    const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
+                    fmv_m[qi] = o[0]; fmv_v[qi] = o[1];
+                }
+            }
+    };
+    auto epilogue_adjoint = [&](int t, const double eps_t, const double (&ytil)[QPW], const double (&fmv_m)[QPW],
+                                const double (&fmv_v)[QPW]) {
+            const double (&gy2in)[QPW] = ytil;
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int q = w + qi * W;
+                if (q < 4) {
+                    const int d = 4 * q + g;
+                    double gfm = 0.0, gfv = 0.0;
+                    if (act[qi] && cvalid) {
+                        const double fmean = fmv_m[qi];        // saved by the forward evaluation (no recompute of P1/P2)
+                        const double fvar = fmv_v[qi];
+                        const double gout = gcar[qi];
+                        if (MODE == MODE_FWD) {
+                            const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // cbfssm.py:227
+                            if (do_cond) {
+                                const double kf1 = a.k_factor - 1.0;
+                                const double vyt = vy[qi] + kf1 * fvar;
+                                const double s = vyt + fvar;
+                                const double rs = 1.0 / s;
+                                const double k = fvar * rs;
+                                const double ydiff = ytil[qi] - fmean;
+                                const double mu = fmean + k * ydiff;
+                                const double omk = 1.0 - k;
+                                const double sig = omk * omk * fvar + k * k * vyt;
+                                const double rf = 1.0 / fvar, rsig = 1.0 / sig;
+                                const double dm = mu - fmean;
+                                // x' = mu + eps sqrt(sig);  kl = .5[log fvar - log sig + (sig + dm^2)/fvar - 1]
+                                const double gmu = gout + a.cL * dm * rf;
+                                const double gsg = gout * eps_t * 0.5 * sqrt(rsig) + a.cL * 0.5 * (rf - rsig);
+                                gfm = -a.cL * dm * rf;
+                                gfv = a.cL * 0.5 * (rf - (sig + dm * dm) * rf * rf);
+                                // mu = fmean + k (ytil - fmean)
+                                gfm += gmu * omk;
+                                double gk = gmu * ydiff;
+                                const double gyt = gmu * k;
+                                // sig = (1-k)^2 fvar + k^2 vyt
+                                gk += gsg * (-2.0 * omk * fvar + 2.0 * k * vyt);
+                                gfv += gsg * omk * omk;
+                                double gvyt = gsg * k * k;
+                                // k = fvar / s ; s = vyt + fvar ; vyt = vy + (kf-1) fvar
+                                gfv += gk * rs;
+                                const double gs = -gk * k * rs;
+                                gvyt += gs;
+                                gfv += gs;
+                                gvy[qi] += gvyt;
+                                gfv += kf1 * gvyt;
+                                if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = gyt;
+                            } else {
+                                // x' = fmean + eps sqrt(fvar), no KL term                           (cbfssm.py:224,234)
+                                gfm = gout;
+                                gfv = gout * eps_t * 0.5 / sqrt(fvar);
+                                if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
+                            }
+                        } else {
+                            // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
+                            const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
+                            const double gtot = gout + (write ? gy2in[qi] : 0.0);
+                            gfm = gtot;
+                            gfv = gtot * eps_t * 0.5 / sqrt(fvar) - (write ? a.cE * 0.5 / fvar : 0.0);
+                        }
+                        gvx[qi] += gfv;
+                        gsig += gfv;
+                    }
+                    gdir[qi] = gfm;
+                    if (d < 16) {
+                        Fm[d * PD + nl] = gfm;
+                        Fv[d * PD + nl] = gfv;
+                    }
+                }
+            }
+    };
+
+    CBF_STAMP_DECL;
+    double hcur[QPW];
+    if (nsteps > 0) {
+        double av[AUXR];
+        load_inputs(t_of(0), hcur, av);
+        store_inputs(xq, hcur, av);
+        double e0, y0[QPW], m0[QPW], v0[QPW];
+        epilogue_load(t_of(0), e0, y0, m0, v0);
+        epilogue_adjoint(t_of(0), e0, y0, m0, v0);
+    }
+    __syncthreads();
+    CBF_STAMP_START();
+#ifdef CBF_REV_STAMPS
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (int step = 0; step < nsteps; ++step) {
+        const int t = t_of(step);
+        const bool has_next = (step + 1 < nsteps);
+        const int tn = has_next ? t_of(step + 1) : t;
+        double* xq = xq0 + (step & 1) * (4 * DK * PD);          // this step's scaled inputs
+        double* xqn = xq0 + ((step + 1) & 1) * (4 * DK * PD);   // filled for the next step during this one
+        bool resample_t = false;
+        if (MODE == MODE_BWD) resample_t = (((t + 1 + run * R) % P) == 0);                    // cbfssm.py:124,127
+
+        // next step's inputs: issued now, written to LDS after the kernel tile
+        double hnext[QPW], auxn[AUXR];
+        if (has_next) load_inputs(tn, hnext, auxn);
         // A2 rows of this wave, if the forward evaluation kept them (consumed after the second barrier)
         d4 a2[RB];
         if (a.a2s) {
@@ -304,76 +413,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 }
             }
         }
-        // ---- D: adjoint of the step epilogue (needs only saved quantities: runs next to the input fill)
-#pragma unroll
-        for (int qi = 0; qi < QPW; ++qi) {
-            const int q = w + qi * W;
-            if (q < 4) {
-                const int d = 4 * q + g;
-                double gfm = 0.0, gfv = 0.0;
-                if (act[qi] && cvalid) {
-                    const double fmean = fmv_m[qi];        // saved by the forward evaluation (no recompute of P1/P2)
-                    const double fvar = fmv_v[qi];
-                    const double gout = gcar[qi];
-                    if (MODE == MODE_FWD) {
-                        const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // cbfssm.py:227
-                        if (do_cond) {
-                            const double kf1 = a.k_factor - 1.0;
-                            const double vyt = vy[qi] + kf1 * fvar;
-                            const double s = vyt + fvar;
-                            const double rs = 1.0 / s;
-                            const double k = fvar * rs;
-                            const double ydiff = ytil[qi] - fmean;
-                            const double mu = fmean + k * ydiff;
-                            const double omk = 1.0 - k;
-                            const double sig = omk * omk * fvar + k * k * vyt;
-                            const double rf = 1.0 / fvar, rsig = 1.0 / sig;
-                            const double dm = mu - fmean;
-                            // x' = mu + eps sqrt(sig);  kl = .5[log fvar - log sig + (sig + dm^2)/fvar - 1]
-                            const double gmu = gout + a.cL * dm * rf;
-                            const double gsg = gout * eps_t * 0.5 * sqrt(rsig) + a.cL * 0.5 * (rf - rsig);
-                            gfm = -a.cL * dm * rf;
-                            gfv = a.cL * 0.5 * (rf - (sig + dm * dm) * rf * rf);
-                            // mu = fmean + k (ytil - fmean)
-                            gfm += gmu * omk;
-                            double gk = gmu * ydiff;
-                            const double gyt = gmu * k;
-                            // sig = (1-k)^2 fvar + k^2 vyt
-                            gk += gsg * (-2.0 * omk * fvar + 2.0 * k * vyt);
-                            gfv += gsg * omk * omk;
-                            double gvyt = gsg * k * k;
-                            // k = fvar / s ; s = vyt + fvar ; vyt = vy + (kf-1) fvar
-                            gfv += gk * rs;
-                            const double gs = -gk * k * rs;
-                            gvyt += gs;
-                            gfv += gs;
-                            gvy[qi] += gvyt;
-                            gfv += kf1 * gvyt;
-                            if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = gyt;
-                        } else {
-                            // x' = fmean + eps sqrt(fvar), no KL term                           (cbfssm.py:224,234)
-                            gfm = gout;
-                            gfv = gout * eps_t * 0.5 / sqrt(fvar);
-                            if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
-                        }
-                    } else {
-                        // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
-                        const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
-                        const double gtot = gout + (write ? gy2in[qi] : 0.0);
-                        gfm = gtot;
-                        gfv = gtot * eps_t * 0.5 / sqrt(fvar) - (write ? a.cE * 0.5 / fvar : 0.0);
-                    }
-                    gvx[qi] += gfv;
-                    gsig += gfv;
-                }
-                gdir[qi] = gfm;
-                if (d < 16) {
-                    Fm[d * PD + nl] = gfm;
-                    Fv[d * PD + nl] = gfv;
-                }
-            }
-        }
-        CBF_STAMP_BARRIER(0);
 
         // ---- B: kernel tile (rows of this wave)
         double bx[DK], xx = 0.0;
@@ -401,6 +440,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 }
             }
         }
+        if (has_next) store_inputs(xqn, hnext, auxn);    // xqn was last read in phase G of the previous step
         CBF_STAMP_BARRIER(1);
 
         // ---- C: A2 rows of this wave, P1/P2
@@ -513,6 +553,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
 
         // ---- F: Kbar, Ebar, input adjoint partials, Zbar~
         CBF_STAMP_MARK0();
+        double eps_n, ytil_n[QPW], fm_n[QPW], fv_n[QPW];     // phase D inputs of the next step, consumed after phase G
+        if (has_next) epilogue_load(tn, eps_n, ytil_n, fm_n, fv_n);
         d4 ebar[RB];
         {
             d4 acc[RB][2];
@@ -641,7 +683,14 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 }
             }
         }
-        // (the barrier at the top of the next step orders the part/xq reads above against the next writes)
+        // ---- D of the next step: same lanes as the carried adjoint just produced (Fm/Fv were last read in phase E)
+        CBF_STAMP_MARK0();
+        if (has_next) {
+            epilogue_adjoint(tn, eps_n, ytil_n, fm_n, fv_n);
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) hcur[qi] = hnext[qi];
+        }
+        CBF_STAMP_MARK(3);
         CBF_STAMP_BARRIER(6);
     }
 

@@ -20,7 +20,7 @@ struct RevGeom {
     typedef RevCfg<NBLK> C;
     static constexpr int JB = (4 * DK + 1 + 15) / 16;
     static constexpr int PSL = (JB > 2 ? JB : 2) * 256;
-    static constexpr int LDS_BASE = 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + C::W * PSL + 64;
+    static constexpr int LDS_BASE = 2 * 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + C::W * PSL + 64;
     static constexpr int LDS_LIMIT = 163840 / 8;
     static constexpr int SLAB = Slab<NBLK, JB, C::STASH>::total;
 };

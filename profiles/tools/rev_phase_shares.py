@@ -37,7 +37,7 @@ for tag, slab, nwg, nstep_total in (('fwd-adjoint', eng.red[:eng.slab_f], ws.n_f
             print('     %-14s compute %5.1f%%  barrier-wait %5.1f%%' % (names[i], 100 * c[i] / tot, 100 * wt[i] / tot))
         if wname == 'wave0':
             marks = small[128:137]
-            mn = ['C loop(25 mfma)', 'C P1P2+store(8)', 'E T1T2(8)', 'E transposes', 'E gMu gS2(8)', 'E gB(28)',
-                  'F loop(25)', 'F xp(8)', 'F transpose+gZ(8)']
+            mn = ['C loop (only without saved A2)', 'A state load -> xq', 'A aux rows', 'A epilogue inputs, A2 issue',
+                  'A/D epilogue adjoint', 'E whole', 'F loop(25)', 'F xp(8)', 'F transpose+gZ(8)']
             for i in range(9):
                 print('        sub %-20s %5.1f%%' % (mn[i], 100 * marks[i] / tot))
