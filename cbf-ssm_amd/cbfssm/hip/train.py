@@ -445,6 +445,7 @@ class TFAdam:
             o += n
         self.lr, self.b1, self.b2, self.eps = float(lr), beta1, beta2, eps
         self.t = 0
+        self.t_dev = torch.zeros((), dtype=torch.float64, device=dev)     # step counter of the graph-captured update
 
     def step(self, grads):
         for k in self.names:
@@ -456,6 +457,20 @@ class TFAdam:
         lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
         self.flat.addcdiv_(self.m, self.v.sqrt().add_(self.eps), value=-lr_t)
 
+    def step_device(self, grads):
+        """The same update with the step counter and lr_t on the device: no host value enters, so the whole step can be
+        captured in a HIP graph and replayed."""
+        for k in self.names:
+            self.gviews[k].copy_(grads[k])
+        self.t_dev.add_(1.0)
+        g = self.gflat
+        self.m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+        b1t = torch.pow(torch.full_like(self.t_dev, self.b1), self.t_dev)
+        b2t = torch.pow(torch.full_like(self.t_dev, self.b2), self.t_dev)
+        lr_t = self.lr * torch.sqrt(1.0 - b2t) / (1.0 - b1t)
+        self.flat.sub_(lr_t * self.m / (self.v.sqrt() + self.eps))
+
     def state_dict(self):
         return {'flat': self.flat.clone(), 'm': self.m.clone(), 'v': self.v.clone(), 't': self.t, 'names': self.names}
 
@@ -464,22 +479,64 @@ class TFAdam:
         self.m.copy_(sd['m'])
         self.v.copy_(sd['v'])
         self.t = int(sd['t'])
+        self.t_dev.fill_(float(self.t))
 
 
 class HipTrainStep:
     """One `sess.run((model.train, model.loss))` (training/trainer.py:40): loss, gradient, Adam update."""
 
-    def __init__(self, config, params, device, dist=None):
+    def __init__(self, config, params, device, dist=None, graph=None):
         self.engine = HipElboGrad(config, device, dist)
         p = {k: _f64(params[k], device).clone() for k in PARAM_NAMES}
         self.opt = TFAdam(p, config['learning_rate'])
         self.params = self.opt.views
+        # HIP graph: a train step is ~60 launches (kernels of this library + the small torch ops of the once-per-step
+        # adjoints and Adam); the small workloads (C1, C2) are launch-bound without it.  One graph per (shapes,
+        # condition), captured at first use.  Not with a process group (the collective stays eager) nor in stash mode.
+        if graph is None:
+            graph = config.get('hip_graph', os.environ.get('CBFSSM_HIP_GRAPH', '1') != '0')
+        self.use_graph = bool(graph) and dist is None and not self.engine.stash
+        self._graphs = {}
 
     def step(self, u, y, noise, condition=True):
+        if self.use_graph:
+            return self._graph_step(u, y, noise, condition)
         loss, grads, terms = self.engine.loss_and_grads(self.params, u, y, noise, condition)
         self.opt.step(grads)
+        self.opt.t_dev.fill_(float(self.opt.t))
         self.last_terms = terms
         return loss
+
+    def _graph_step(self, u, y, noise, condition):
+        dev = self.engine.device
+        u, y = _f64(u, dev), _f64(y, dev)
+        key = (tuple(u.shape), tuple(y.shape), bool(condition))
+        g = self._graphs.get(key)
+        names = ('hid_b', 'eps_b', 'eps_f')
+        if g is None:
+            g = {'u': u.clone(), 'y': y.clone(), 'noise': {k: _f64(noise[k], dev).clone() for k in names}}
+            # warm-up outside the capture (workspaces, kernel attributes); the parameters are not touched
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.engine.loss_and_grads(self.params, g['u'], g['y'], g['noise'], condition)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss, grads, terms = self.engine.loss_and_grads(self.params, g['u'], g['y'], g['noise'], condition)
+                self.opt.step_device(grads)
+            g.update(graph=graph, loss=loss, terms=terms)
+            self._graphs[key] = g
+        else:
+            g['u'].copy_(u)
+            g['y'].copy_(y)
+            for k in names:
+                g['noise'][k].copy_(_f64(noise[k], dev))
+        g['graph'].replay()
+        self.opt.t += 1
+        self.last_terms = g['terms']
+        return g['loss'].clone()
 
 
 def train_step_smoke():

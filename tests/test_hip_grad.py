@@ -79,6 +79,28 @@ def test_train_step_decreases_loss_and_matches_tf_adam_rule():
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize('split', [None, '1'])
+def test_graph_captured_train_step_equals_eager(split, monkeypatch):
+    """HipTrainStep replays one captured HIP graph per step (default); the eager path must give the same parameters,
+    also with the chain-group split on two streams inside the capture and with fresh inputs every step."""
+    if split:
+        monkeypatch.setenv('CBFSSM_SPLIT_MAIN', split)
+    w = syn.tiny(M=20, T=16, B=4, S=8, learning_rate=0.01)
+    cfg = w.model_config()
+    p = syn.make_params(w)
+    mk = lambda graph: train.HipTrainStep(cfg, {k: torch.tensor(v, device=DEV) for k, v in p.items()}, DEV, graph=graph)
+    sg, se = mk(True), mk(False)
+    assert sg.use_graph and not se.use_graph
+    for it in range(4):
+        u, y = syn.make_inputs(w, seed=10 + it)
+        noise = syn.make_noise(w, seed=20 + it)
+        lg, le = float(sg.step(u, y, noise)), float(se.step(u, y, noise))
+        assert abs(lg - le) <= 1e-12 * abs(le), (it, lg, le)
+        for k in train.PARAM_NAMES:
+            assert torch.allclose(sg.params[k], se.params[k], rtol=1e-12, atol=1e-14), (it, k)
+    assert sg.opt.t == se.opt.t == 4 and float(sg.opt.t_dev) == 4.0
+
+
 @pytest.mark.parametrize('kw,gib', [
     (dict(M=130, dim_x=9, dim_u=3, dim_y=2, T=14, B=2, S=9, recog_len=3, k_factor=20.), 4.0),       # tile height 10
     (dict(M=200, dim_x=14, dim_u=7, dim_y=7, T=11, B=1, S=20, recog_len=2, k_factor=50., var_y=0.05 ** 2), 4.0),   # C4 tile
