@@ -20,8 +20,13 @@ SYMBOLS = (
     'cbfssm_elbo_combine_f64', 'cbfssm_rev_workgroups', 'cbfssm_forward_pass_bwd_f64',
     'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64', 'cbfssm_bwd_segments', 'cbfssm_forward_pass_bwd_ex_f64',
     'cbfssm_backward_pass_bwd_ex_f64', 'cbfssm_half_forward_pass_f64', 'cbfssm_half_forward_pass_bwd_f64',
-    'cbfssm_saved_a2_elems',
+    'cbfssm_saved_a2_elems', 'cbfssm_param_layout_init', 'cbfssm_constrain_f64', 'cbfssm_train_tail_work_elems',
+    'cbfssm_train_tail_f64', 'cbfssm_adam_step_f64',
 )
+
+
+class ParamLayout(C.Structure):
+    _fields_ = [('off', C.c_int64 * 12), ('total', C.c_int64)] + [(n, C.c_int32) for n in ('M', 'D', 'dim_x', 'dim_y')]
 
 
 class PackLayout(C.Structure):
@@ -68,6 +73,13 @@ def load():
     lib.cbfssm_backward_pass_partials.argtypes = [C.POINTER(Problem)]
     lib.cbfssm_backward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 12
     lib.cbfssm_forward_pass_partials.restype = i64
+    lib.cbfssm_param_layout_init.argtypes = [ip, ip, ip, ip, C.POINTER(ParamLayout)]
+    lib.cbfssm_constrain_f64.argtypes = [C.POINTER(ParamLayout), vp, vp, vp]
+    lib.cbfssm_train_tail_work_elems.restype = i64
+    lib.cbfssm_train_tail_work_elems.argtypes = [C.POINTER(PackLayout), C.POINTER(PackLayout)]
+    lib.cbfssm_train_tail_f64.argtypes = ([C.POINTER(ParamLayout), C.POINTER(PackLayout), vp, C.POINTER(PackLayout), vp, vp,
+                                          vp, vp, i64, vp, vp, vp, vp, vp])
+    lib.cbfssm_adam_step_f64.argtypes = [i64, vp, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp]
     lib.cbfssm_saved_a2_elems.restype = i64
     lib.cbfssm_saved_a2_elems.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout), ip]
     lib.cbfssm_forward_pass_partials.argtypes = [C.POINTER(Problem)]
@@ -86,10 +98,17 @@ def load():
     lib.cbfssm_reduce_partials_f64.argtypes = [vp, i64, i64, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if fn.restype is C.c_int or name.endswith('_f64') or name in ('cbfssm_gp_pack_layout', 'cbfssm_bwd_segments'):
+        if fn.restype is C.c_int or name.endswith('_f64') or name in ('cbfssm_gp_pack_layout', 'cbfssm_bwd_segments',
+                                                                        'cbfssm_param_layout_init'):
             fn.restype = ip
     _lib = lib
     return lib
+
+
+def param_layout(M, dim_x, dim_u, dim_y):
+    pl = ParamLayout()
+    check(load().cbfssm_param_layout_init(int(M), int(dim_x), int(dim_u), int(dim_y), C.byref(pl)), 'cbfssm_param_layout_init')
+    return pl
 
 
 def check(rc, what):

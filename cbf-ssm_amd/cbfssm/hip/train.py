@@ -28,6 +28,28 @@ PARAM_NAMES = (
 LOG2PI = math.log(2.0 * math.pi)
 
 
+class FlatDict(dict):
+    """name -> tensor views of ONE flat float64 device vector (`.flat`), in PARAM_NAMES order: lets the train-step tail
+    (cbfssm_train_tail_f64, cbfssm_adam_step_f64) work on the whole parameter / gradient set in single launches."""
+    flat = None
+
+
+def _flat_views(flat, pl, dim_u):
+    M, D, dx, dy = pl.M, pl.D, pl.dim_x, pl.dim_y
+    shapes = []
+    for Do in (dx, dx - dy):
+        shapes += [(M, D), (M, Do), (M, Do), (1,), (D,)]
+    shapes += [(dx,), (dx,)]
+    out = FlatDict()
+    for k, name in enumerate(PARAM_NAMES):
+        n = 1
+        for s in shapes[k]:
+            n *= s
+        out[name] = flat[pl.off[k]:pl.off[k] + n].view(*shapes[k])
+    out.flat = flat
+    return out
+
+
 def _unpack_c(v, nrb, ncb):
     """MFMA accumulator image [rb][cb][r][lane] -> dense (16*nrb, 16*ncb); row = 16rb + (lane>>4) + 4r."""
     return v.view(nrb, ncb, 4, 4, 16).permute(0, 2, 3, 1, 4).reshape(16 * nrb, 16 * ncb)
@@ -60,12 +82,40 @@ class HipElboGrad:
         self.nred = self.slab_f + self.slab_b + 3 + self.dim_y
         self.red = torch.zeros(self.nred, dtype=torch.float64, device=self.device)
         self._ws = {}
+        # train-step tail in HIP (positivity transforms, K_mm/K^-1 adjoint + prior KL, chain rule): flat vectors in
+        # PARAM_NAMES order.  CBFSSM_TORCH_TAIL=1 keeps the tensor-library restatement below (same numbers, ~170 launches).
+        self.pl = _l.param_layout(self.M, self.dim_x, self.dim_u, self.dim_y)
+        f = dict(dtype=torch.float64, device=self.device)
+        self.cflat = torch.zeros(self.pl.total, **f)
+        self.gflat = torch.zeros(self.pl.total, **f)
+        self.fused_tail = self.has_adjoint and not os.environ.get('CBFSSM_TORCH_TAIL')
+        if self.has_adjoint:
+            nw = int(_l.load().cbfssm_train_tail_work_elems(C.byref(self.pack_f.layout), C.byref(self.pack_b.layout)))
+            self.tail_work = torch.zeros(max(nw, 1), **f)
 
     def _need_adjoint(self):
         if not self.has_adjoint:
             raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d)' % (self.M, self.pack_f.layout.NBLK))
 
     # ---- forward evaluation (keeps what the adjoint needs)
+    def _flat(self, params):
+        """The twelve tensors as one flat vector: the optimizer's own storage when `params` are its views."""
+        flat = getattr(params, 'flat', None)
+        if flat is not None and flat.numel() == self.pl.total and flat.device == self.device:
+            return flat
+        return torch.cat([_f64(params[k], self.device).reshape(-1) for k in PARAM_NAMES])
+
+    def _constrained_flat(self, pflat):
+        """softplus + 1e-10 of every *_unc tensor in one launch; returns (p views of pflat, c dict of cflat views)."""
+        _l.check(_l.load().cbfssm_constrain_f64(C.byref(self.pl), _ptr(pflat), _ptr(self.cflat), _stream()),
+                 'cbfssm_constrain_f64')
+        p = _flat_views(pflat, self.pl, self.dim_u)
+        cv = _flat_views(self.cflat, self.pl, self.dim_u)
+        c = {'var_x': cv['var_x_unc'], 'var_y': cv['var_y_unc']}
+        for g in 'fb':
+            c[g + '.ls'], c[g + '.var'], c[g + '.zvar'] = cv[g + '.lengthscales_unc'], cv[g + '.variance_unc'], cv[g + '.zeta_var_unc']
+        return p, c
+
     def _constrained(self, p):
         c = {}
         for g in 'fb':
@@ -80,12 +130,11 @@ class HipElboGrad:
         """Loss only (what Trainer's test pass and Outputs fetch): returns (loss 0-d tensor, terms, workspace)."""
         dev = self.device
         cfg = self.config
-        p = {k: _f64(params[k], dev) for k in PARAM_NAMES}
         u, y = _f64(u, dev), _f64(y, dev)
         B, T = u.shape[0], u.shape[1]
         prob = _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, cfg['recog_len'],
                                cfg['k_factor'], condition)
-        c = self._constrained(p)
+        p, c = self._constrained_flat(self._flat(params))
         ops.prepare_pair(self.pack_f, (p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar']),
                          self.pack_b, (p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar']))
         key = ('eval', B, T)
@@ -135,12 +184,12 @@ class HipElboGrad:
         lib = _l.load()
         dev = self.device
         cfg = self.config
-        p = {k: _f64(params[k], dev) for k in PARAM_NAMES}
         u, y = _f64(u, dev), _f64(y, dev)
         B, T = u.shape[0], u.shape[1]
         prob = _l.make_problem(B, self.S, T, self.dim_x, self.dim_u, self.dim_y, self.M, cfg['recog_len'],
                                cfg['k_factor'], condition)
-        c = self._constrained(p)
+        pflat = self._flat(params)
+        p, c = self._constrained_flat(pflat)
         ops.prepare_pair(self.pack_f, (p['f.zeta_pos'], c['f.ls'], c['f.var'], p['f.zeta_mean'], c['f.zvar']),
                          self.pack_b, (p['b.zeta_pos'], c['b.ls'], c['b.var'], p['b.zeta_mean'], c['b.zvar']))
         ws = self._workspace(prob)
@@ -191,7 +240,21 @@ class HipElboGrad:
                 all_reduce_sum(gB_f, self.dist)
                 all_reduce_sum(gB_b, self.dist)
 
-        # ---- once-per-step adjoints and the chain through the positivity transforms
+        loglik, kl_x, entropy = tail[0], tail[1], tail[2]
+        kl_z_f, kl_z_b = self.pack_f.scal[_l.SCAL_KLZ], self.pack_b.scal[_l.SCAL_KLZ]
+        elbo = loglik * cL - kl_x * cL + entropy * cE - kl_z_f - kl_z_b                    # cbfssm.py:258-261
+        terms = {'loglik': loglik, 'kl_x': kl_x, 'entropy': entropy, 'kl_z_f': kl_z_f, 'kl_z_b': kl_z_b,
+                 'info': ws.out[7]}
+        if self.fused_tail:
+            Mp = self.pack_f.layout.Mp
+            rc = lib.cbfssm_train_tail_f64(C.byref(self.pl), C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
+                                           C.byref(self.pack_b.layout), _ptr(self.pack_b.buf), _ptr(red), _ptr(gB_f),
+                                           _ptr(gB_b), Mp, _ptr(pflat), _ptr(self.cflat), _ptr(self.tail_work),
+                                           _ptr(self.gflat), st)
+            _l.check(rc, 'cbfssm_train_tail_f64')
+            return -elbo, _flat_views(self.gflat, self.pl, self.dim_u), terms
+
+        # ---- once-per-step adjoints and the chain through the positivity transforms (tensor-library restatement)
         grads = {}
         gvx = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
         gvy = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
@@ -211,11 +274,6 @@ class HipElboGrad:
         grads['var_x_unc'] = gvx * torch.sigmoid(p['var_x_unc'])
         grads['var_y_unc'] = gvy * torch.sigmoid(p['var_y_unc'])
 
-        loglik, kl_x, entropy = tail[0], tail[1], tail[2]
-        kl_z_f, kl_z_b = self.pack_f.scal[_l.SCAL_KLZ], self.pack_b.scal[_l.SCAL_KLZ]
-        elbo = loglik * cL - kl_x * cL + entropy * cE - kl_z_f - kl_z_b                    # cbfssm.py:258-261
-        terms = {'loglik': loglik, 'kl_x': kl_x, 'entropy': entropy, 'kl_z_f': kl_z_f, 'kl_z_b': kl_z_b,
-                 'info': ws.out[7]}
         return -elbo, grads, terms
 
     # ---- chain-group split: chains never interact, so a pass can be issued in two pieces on two HIP streams.  When the
@@ -437,20 +495,40 @@ class TFAdam:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.gflat = torch.zeros_like(self.flat)
-        self.views, self.gviews = {}, {}
+        self.views, self.gviews = FlatDict(), {}
+        self.views.flat = self.flat
         o = 0
         for k, n in zip(self.names, sizes):
             self.views[k] = self.flat[o:o + n].view(params[k].shape)
             self.gviews[k] = self.gflat[o:o + n].view(params[k].shape)
             o += n
         self.lr, self.b1, self.b2, self.eps = float(lr), beta1, beta2, eps
-        self.t = 0
-        self.t_dev = torch.zeros((), dtype=torch.float64, device=dev)     # step counter of the graph-captured update
+        self.t_dev = torch.zeros(1, dtype=torch.float64, device=dev)      # step counter as the update kernel sees it
+        self._t = 0
+
+    @property
+    def t(self):
+        return self._t
+
+    @t.setter
+    def t(self, value):
+        self._t = int(value)
+        self.t_dev.fill_(float(value))
 
     def step(self, grads):
+        gflat = getattr(grads, 'flat', None)
+        if gflat is not None and gflat.is_cuda and gflat.numel() == self.flat.numel():
+            # the whole update in one launch on the flat vectors; the step counter lives on the device, so the call is
+            # the same inside a captured HIP graph
+            rc = _l.load().cbfssm_adam_step_f64(self.flat.numel(), _ptr(self.flat), _ptr(gflat), _ptr(self.m),
+                                                _ptr(self.v), _ptr(self.t_dev), self.lr, self.b1, self.b2, self.eps,
+                                                _stream())
+            _l.check(rc, 'cbfssm_adam_step_f64')
+            self._t += 1
+            return
         for k in self.names:
             self.gviews[k].copy_(grads[k])
-        self.t += 1
+        self.t = self._t + 1
         g = self.gflat
         self.m.mul_(self.b1).add_(g, alpha=1 - self.b1)
         self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
@@ -463,6 +541,7 @@ class TFAdam:
         for k in self.names:
             self.gviews[k].copy_(grads[k])
         self.t_dev.add_(1.0)
+        self._t += 1
         g = self.gflat
         self.m.mul_(self.b1).add_(g, alpha=1 - self.b1)
         self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
@@ -479,7 +558,6 @@ class TFAdam:
         self.m.copy_(sd['m'])
         self.v.copy_(sd['v'])
         self.t = int(sd['t'])
-        self.t_dev.fill_(float(self.t))
 
 
 class HipTrainStep:
@@ -503,7 +581,6 @@ class HipTrainStep:
             return self._graph_step(u, y, noise, condition)
         loss, grads, terms = self.engine.loss_and_grads(self.params, u, y, noise, condition)
         self.opt.step(grads)
-        self.opt.t_dev.fill_(float(self.opt.t))
         self.last_terms = terms
         return loss
 
@@ -525,7 +602,11 @@ class HipTrainStep:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 loss, grads, terms = self.engine.loss_and_grads(self.params, g['u'], g['y'], g['noise'], condition)
-                self.opt.step_device(grads)
+                if getattr(grads, 'flat', None) is not None:
+                    self.opt.step(grads)
+                else:
+                    self.opt.step_device(grads)
+                self.opt._t -= 1                  # capture does not execute; every replay counts below
             g.update(graph=graph, loss=loss, terms=terms)
             self._graphs[key] = g
         else:
@@ -534,7 +615,7 @@ class HipTrainStep:
             for k in names:
                 g['noise'][k].copy_(_f64(noise[k], dev))
         g['graph'].replay()
-        self.opt.t += 1
+        self.opt._t += 1
         self.last_terms = g['terms']
         return g['loss'].clone()
 

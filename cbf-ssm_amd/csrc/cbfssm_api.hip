@@ -18,7 +18,7 @@ namespace cbfssm {
 static thread_local char g_err[512] = "";
 static double* g_dbg = nullptr;   // diagnostic builds only (cbfssm_debug_set_buffer)
 
-static int fail(int code, const char* fmt, ...)
+int fail(int code, const char* fmt, ...)   // also used by cbfssm_tail.hip
 {
     va_list ap;
     va_start(ap, fmt);

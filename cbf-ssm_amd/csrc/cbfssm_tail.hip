@@ -1,0 +1,340 @@
+// Once-per-step tail of a train step: positivity transforms, the O(M^3) adjoint of K_mm -> K^-1 with the prior-KL
+// gradient, the chain through the transforms, and the TF-1.8 Adam update.  These are ~170 tiny tensor ops when written
+// in a tensor library (half of a C1 train step); here they are five launches.
+//
+// Reference call sites: tf_transform.py:19-21 (softplus + 1e-10), gp_tf.py:33-49 (RBF), :129-130 (K_mm, Cholesky),
+// :163-172 (prior KL), base_model.py:34-36 (tf.gradients through all of it), cbfssm.py:273-275 (AdamOptimizer).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/cbfssm_hip.h"
+
+namespace cbfssm {
+
+int fail(int rc, const char* fmt, ...);   // cbfssm_api.hip
+
+struct GpTail {
+    const double* slab;       // reduced adjoint slab of this GP (Slab<> layout, cbfssm_adjoint.hpp)
+    const double* gB_dense;   // stash mode: dense K^-1 adjoint [.][gB_ld]; else NULL (C-layout image inside the slab)
+    int64_t gB_ld;
+    const double* Kinv;       // [M][M]
+    const double* Kmm;        // [M][M]
+    const double* Zs;         // [M][D]   z / lengthscale
+    double* T;                // scratch [M][max(M,32)]
+    double* G2;               // scratch [M][M]
+    const double* zmean;      // [M][Do]
+    const double* zvar;       // [M][Do]  constrained
+    const double* ls;         // [D]      constrained
+    const double* var;        // [1]      constrained
+    const double* zvar_unc;
+    const double* var_unc;
+    const double* ls_unc;
+    double* g_z;              // [M][D]
+    double* g_mu;             // [M][Do]
+    double* g_s2;             // [M][Do]  w.r.t. the unconstrained variable
+    double* g_var;            // [1]
+    double* g_ls;             // [D]
+    int M, D, Do, NBLK, JB, stash;
+};
+
+struct TailArgs {
+    GpTail gp[2];
+    const double* vx_unc;
+    const double* vy_unc;
+    double* g_vx;
+    double* g_vy;
+    const double* tail;       // [3 + dim_y]: loglik, kl_x, entropy, d loss/d var_y from the log-likelihood
+    int dim_x, dim_y;
+};
+
+__device__ __forceinline__ double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// element (row, col) of an MFMA C-layout image [nrb][ncb][4][64]: row = 16 rb + (lane >> 4) + 4 r, col = 16 cb + (lane & 15)
+__device__ __forceinline__ double c_image(const double* img, int ncb, int row, int col)
+{
+    const int rb = row >> 4, rr = row & 15, cb = col >> 4, nl = col & 15;
+    return img[((rb * ncb + cb) * 4 + (rr >> 2)) * 64 + 16 * (rr & 3) + nl];
+}
+
+__device__ __forceinline__ double block_sum_t(double v, double* red, int tid, int nt)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < (nt >> 6); ++i) s += red[i];   // fixed order: deterministic
+    return s;
+}
+
+// G = Kinvbar (data) + Kinvbar (prior KL):  0.5 (diag(sum_d zvar) + zmean zmean^T)          (gp_tf.py:163-172)
+__device__ __forceinline__ double g_elem(const GpTail& p, int k, int j)
+{
+    double v;
+    if (p.gB_dense) v = p.gB_dense[int64_t(k) * p.gB_ld + j];
+    else v = c_image(p.slab + 2 * p.NBLK * 256, p.NBLK, k, j);
+    double dot = 0.0;
+    for (int d = 0; d < p.Do; ++d) dot = fma(p.zmean[k * p.Do + d], p.zmean[j * p.Do + d], dot);
+    if (k == j)
+        for (int d = 0; d < p.Do; ++d) dot += p.zvar[k * p.Do + d];
+    return v + 0.5 * dot;
+}
+
+// STAGE 0: T = Kinv G.   STAGE 1: G2 = (-T Kinv + 0.5 Do Kinv) o Kmm   (K^-1 = (K_mm + jitter I)^-1, log det of the KL)
+template <int STAGE>
+__global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
+{
+    const GpTail& p = a.gp[blockIdx.z];
+    const int M = p.M;
+    __shared__ double As[16][17], Bs[16][17];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    if (int(blockIdx.y) * 16 >= M || int(blockIdx.x) * 16 >= M) return;
+    const double* A = (STAGE == 0) ? p.Kinv : p.T;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < M; k0 += 16) {
+        As[ty][tx] = (i < M && k0 + tx < M) ? A[int64_t(i) * M + k0 + tx] : 0.0;
+        double b = 0.0;
+        if (k0 + ty < M && j < M) b = (STAGE == 0) ? g_elem(p, k0 + ty, j) : p.Kinv[int64_t(k0 + ty) * M + j];
+        Bs[ty][tx] = b;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) acc = fma(As[ty][kk], Bs[kk][tx], acc);
+        __syncthreads();
+    }
+    if (i < M && j < M) {
+        if (STAGE == 0) p.T[int64_t(i) * M + j] = acc;
+        else {
+            const double kinv = p.Kinv[int64_t(i) * M + j];
+            p.G2[int64_t(i) * M + j] = (-acc + 0.5 * p.Do * kinv) * p.Kmm[int64_t(i) * M + j];
+        }
+    }
+}
+
+// One workgroup per GP: everything that is O(M^2 D) or smaller, and the chain through the positivity transforms.
+__global__ __launch_bounds__(256) void tail_finish(TailArgs a)
+{
+    const GpTail& p = a.gp[blockIdx.x];
+    const int M = p.M, D = p.D, Do = p.Do, NBLK = p.NBLK, JB = p.JB;
+    const int tid = threadIdx.x, NT = 256;
+    __shared__ double wsrow[320];
+    __shared__ double red[8];
+    __shared__ double col[32];
+    const double* gMu = p.slab;
+    const double* gS2 = p.slab + NBLK * 256;
+    const double* gZ = p.slab + 2 * NBLK * 256 + (p.stash ? 0 : NBLK * NBLK * 256);
+    const double* small = gZ + NBLK * JB * 256;
+    const double* G2 = p.G2;
+
+    // K = var exp(-0.5 d2(z~)): Kbar o K = G2;  Wd = -0.5 G2, Ws = Wd + Wd^T                           (gp_tf.py:33-49)
+    double tot = 0.0;
+    for (int i = tid; i < M; i += NT) {
+        double s = 0.0;
+        for (int j = 0; j < M; ++j) {
+            const double gij = G2[int64_t(i) * M + j];
+            s += gij + G2[int64_t(j) * M + i];
+            tot += gij;
+        }
+        wsrow[i] = -0.5 * s;
+    }
+    tot = block_sum_t(tot, red, tid, NT);
+    __syncthreads();
+
+    // Z~bar = Ebar x~^T - z~ o rowsum(Ebar) + 2 (rowsum(Ws) o z~ - Ws z~);   zbar = Z~bar / ls
+    double* gzs = p.T;                      // [M][D]: Z~bar o z~, for the lengthscale column sums
+    for (int idx = tid; idx < M * D; idx += NT) {
+        const int i = idx / D, j = idx - i * D;
+        double wz = 0.0;
+        for (int k = 0; k < M; ++k) wz = fma(G2[int64_t(i) * M + k] + G2[int64_t(k) * M + i], p.Zs[k * D + j], wz);
+        wz *= -0.5;
+        const double zs = p.Zs[i * D + j];
+        const double gzt = c_image(gZ, JB, i, j) - zs * c_image(gZ, JB, i, D) + 2.0 * (wsrow[i] * zs - wz);
+        p.g_z[idx] = gzt / p.ls[j];
+        gzs[idx] = gzt * zs;
+    }
+    __syncthreads();
+    if (tid < D) {
+        double s = 0.0;
+        for (int i = 0; i < M; ++i) s += gzs[i * D + tid];
+        col[tid] = s;
+    }
+    __syncthreads();
+    if (tid < D) {
+        const double glx = small[32 + tid];
+        p.g_ls[tid] = -(col[tid] + glx) / p.ls[tid] * sigmoid(p.ls_unc[tid]);
+    }
+    if (tid == 0) {
+        const double var = p.var[0];
+        p.g_var[0] = (tot / var + small[96] + small[97] / var) * sigmoid(p.var_unc[0]);
+    }
+    // inducing mean / variance: data part from the slab + prior KL                                    (gp_tf.py:163-172)
+    for (int idx = tid; idx < M * Do; idx += NT) {
+        const int i = idx / Do, d = idx - i * Do;
+        double km = 0.0;
+        for (int k = 0; k < M; ++k) km = fma(p.Kinv[int64_t(i) * M + k], p.zmean[k * Do + d], km);
+        p.g_mu[idx] = c_image(gMu, 1, i, d) + km;
+        const double gs2 = c_image(gS2, 1, i, d) + 0.5 * (p.Kinv[int64_t(i) * M + i] - 1.0 / p.zvar[idx]);
+        p.g_s2[idx] = gs2 * sigmoid(p.zvar_unc[idx]);
+    }
+    // process / observation noise (workgroup of gp_f): per-dimension sums of both slabs + the log-likelihood's pull
+    if (blockIdx.x == 0 && tid < a.dim_x) {
+        const GpTail& pb = a.gp[1];
+        const double* small_b = pb.slab + 2 * pb.NBLK * 256 + (pb.stash ? 0 : pb.NBLK * pb.NBLK * 256) + pb.NBLK * pb.JB * 256;
+        double gvx = small[tid];
+        if (tid < pb.Do) gvx += small_b[tid];
+        double gvy = small[16 + tid];
+        if (tid < a.dim_y) gvy += a.tail[3 + tid];
+        a.g_vx[tid] = gvx * sigmoid(a.vx_unc[tid]);
+        a.g_vy[tid] = gvy * sigmoid(a.vy_unc[tid]);
+    }
+}
+
+struct ConstrainArgs {
+    const double* p;
+    double* c;
+    int64_t off[13];          // segment starts (PARAM order) + total
+    int unc[12];
+};
+
+__global__ __launch_bounds__(256) void constrain_kernel(ConstrainArgs a)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= a.off[12]) return;
+    int seg = 0;
+#pragma unroll
+    for (int s = 1; s < 12; ++s) seg += (i >= a.off[s]);
+    const double x = a.p[i];
+    // softplus(x) + 1e-10                                                                           (tf_transform.py:19-21)
+    a.c[i] = a.unc[seg] ? (fmax(x, 0.0) + log1p(exp(-fabs(x))) + 1e-10) : x;
+}
+
+__global__ void adam_tick_kernel(double* t) { t[0] += 1.0; }
+
+// tf.train.AdamOptimizer (TF 1.8): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t);  p -= lr_t m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(int64_t n, double* p, const double* g, double* m, double* v, const double* t,
+                                                   double lr, double b1, double b2, double eps)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double tt = t[0];
+    const double lr_t = lr * sqrt(1.0 - pow(b2, tt)) / (1.0 - pow(b1, tt));
+    const double gi = g[i];
+    const double mi = b1 * m[i] + (1.0 - b1) * gi;
+    const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrt(vi) + eps);
+}
+
+}  // namespace cbfssm
+
+using namespace cbfssm;
+
+extern "C" {
+
+int cbfssm_param_layout_init(int M, int dim_x, int dim_u, int dim_y, cbfssm_param_layout* out)
+{
+    if (!out) return fail(-1, "null layout");
+    if (M < 1 || dim_x < 1 || dim_u < 0 || dim_y < 1 || dim_y > dim_x) return fail(-1, "bad dimensions");
+    const int D = dim_x + dim_u;
+    const int Do[2] = {dim_x, dim_x - dim_y};
+    int64_t o = 0;
+    int k = 0;
+    for (int g = 0; g < 2; ++g) {
+        out->off[k++] = o; o += int64_t(M) * D;        // zeta_pos
+        out->off[k++] = o; o += int64_t(M) * Do[g];    // zeta_mean
+        out->off[k++] = o; o += int64_t(M) * Do[g];    // zeta_var_unc
+        out->off[k++] = o; o += 1;                     // variance_unc
+        out->off[k++] = o; o += D;                     // lengthscales_unc
+    }
+    out->off[k++] = o; o += dim_x;                     // var_x_unc
+    out->off[k++] = o; o += dim_x;                     // var_y_unc
+    out->total = o;
+    out->M = M; out->D = D; out->dim_x = dim_x; out->dim_y = dim_y;
+    return 0;
+}
+
+int cbfssm_constrain_f64(const cbfssm_param_layout* pl, const double* pflat, double* cflat, void* stream)
+{
+    if (!pl || !pflat || !cflat) return fail(-1, "null pointer");
+    ConstrainArgs a;
+    a.p = pflat; a.c = cflat;
+    for (int i = 0; i < 12; ++i) a.off[i] = pl->off[i];
+    a.off[12] = pl->total;
+    static const int unc[12] = {0, 0, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1};
+    memcpy(a.unc, unc, sizeof(unc));
+    const unsigned nb = unsigned((pl->total + 255) / 256);
+    hipLaunchKernelGGL(constrain_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(-int(e) - 1000, "constrain launch failed");
+}
+
+int64_t cbfssm_train_tail_work_elems(const cbfssm_pack_layout* Lf, const cbfssm_pack_layout* Lb)
+{
+    if (!Lf || !Lb) return -1;
+    auto one = [](const cbfssm_pack_layout* L) { return int64_t(L->M) * (L->M > 32 ? L->M : 32) + int64_t(L->M) * L->M; };
+    return one(Lf) + one(Lb);
+}
+
+int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layout* Lf, const double* pack_f,
+                          const cbfssm_pack_layout* Lb, const double* pack_b, const double* red, const double* gB_dense_f,
+                          const double* gB_dense_b, int64_t gB_ld, const double* pflat, const double* cflat, double* work,
+                          double* gflat, void* stream)
+{
+    if (!pl || !Lf || !Lb || !pack_f || !pack_b || !red || !pflat || !cflat || !work || !gflat)
+        return fail(-1, "null pointer");
+    if (Lf->M != pl->M || Lb->M != pl->M || Lf->D != pl->D || Lb->D != pl->D) return fail(-1, "layouts disagree");
+    if (Lf->Do != pl->dim_x || Lb->Do != pl->dim_x - pl->dim_y) return fail(-1, "output dims disagree");
+    if (Lf->rev_slab <= 0 || Lb->rev_slab <= 0) return fail(-3, "no adjoint slab for M=%d", Lf->M);
+    if (Lf->M > 320 || pl->D > 32) return fail(-3, "tail kernel limits: M <= 320, D <= 32");
+    if ((Lf->rev_stash != 0) != (gB_dense_f != nullptr) || (Lb->rev_stash != 0) != (gB_dense_b != nullptr))
+        return fail(-1, "dense K^-1 adjoints are required exactly in stash mode");
+    TailArgs a;
+    memset(&a, 0, sizeof(a));
+    const cbfssm_pack_layout* L[2] = {Lf, Lb};
+    const double* pack[2] = {pack_f, pack_b};
+    const double* gBd[2] = {gB_dense_f, gB_dense_b};
+    const double* slab = red;
+    double* w = work;
+    for (int g = 0; g < 2; ++g) {
+        GpTail& p = a.gp[g];
+        const int M = L[g]->M;
+        p.slab = slab; slab += L[g]->rev_slab;
+        p.gB_dense = gBd[g]; p.gB_ld = gB_ld;
+        p.Kinv = pack[g] + L[g]->Kinv; p.Kmm = pack[g] + L[g]->Kmm; p.Zs = pack[g] + L[g]->Zs;
+        p.T = w; w += int64_t(M) * (M > 32 ? M : 32);
+        p.G2 = w; w += int64_t(M) * M;
+        const int64_t* off = pl->off + 5 * g;
+        p.zmean = cflat + off[1]; p.zvar = cflat + off[2]; p.var = cflat + off[3]; p.ls = cflat + off[4];
+        p.zvar_unc = pflat + off[2]; p.var_unc = pflat + off[3]; p.ls_unc = pflat + off[4];
+        p.g_z = gflat + off[0]; p.g_mu = gflat + off[1]; p.g_s2 = gflat + off[2]; p.g_var = gflat + off[3];
+        p.g_ls = gflat + off[4];
+        p.M = M; p.D = L[g]->D; p.Do = L[g]->Do; p.NBLK = L[g]->NBLK; p.JB = L[g]->JB; p.stash = L[g]->rev_stash;
+    }
+    a.tail = slab;
+    a.vx_unc = pflat + pl->off[10]; a.vy_unc = pflat + pl->off[11];
+    a.g_vx = gflat + pl->off[10]; a.g_vy = gflat + pl->off[11];
+    a.dim_x = pl->dim_x; a.dim_y = pl->dim_y;
+    const unsigned nb = unsigned((pl->M + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tail_gemm<0>, dim3(nb, nb, 2), dim3(16, 16), 0, st, a);
+    hipLaunchKernelGGL(tail_gemm<1>, dim3(nb, nb, 2), dim3(16, 16), 0, st, a);
+    hipLaunchKernelGGL(tail_finish, dim3(2), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(-int(e) - 1000, "train tail launch failed");
+}
+
+int cbfssm_adam_step_f64(int64_t n, double* pflat, const double* gflat, double* m, double* v, double* t_dev, double lr,
+                         double beta1, double beta2, double eps, void* stream)
+{
+    if (n < 1 || !pflat || !gflat || !m || !v || !t_dev) return fail(-1, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, t_dev);
+    hipLaunchKernelGGL(adam_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, n, pflat, gflat, m, v,
+                       (const double*)t_dev, lr, beta1, beta2, eps);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(-int(e) - 1000, "adam launch failed");
+}
+
+}  // extern "C"

@@ -253,6 +253,45 @@ int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_l
 #define CBFSSM_REDUCE_SPLIT 32
 int cbfssm_reduce_partials_f64(double* gpart, int64_t slab, int64_t nwg, double* out, void* stream);
 
+/*
+ * ---- once-per-step tail of a train step ------------------------------------------------------------------------------
+ * The twelve trainable tensors of CBFSSM._setup_vars (cbfssm.py:30-58) as ONE flat float64 vector, in this order:
+ *   f.zeta_pos (M,D) f.zeta_mean (M,dim_x) f.zeta_var_unc (M,dim_x) f.variance_unc (1) f.lengthscales_unc (D)
+ *   b.zeta_pos (M,D) b.zeta_mean (M,dob)   b.zeta_var_unc (M,dob)   b.variance_unc (1) b.lengthscales_unc (D)
+ *   var_x_unc (dim_x) var_y_unc (dim_x)                      D = dim_x + dim_u, dob = dim_x - dim_y
+ */
+typedef struct cbfssm_param_layout {
+    int64_t off[12];
+    int64_t total;
+    int32_t M, D, dim_x, dim_y;
+} cbfssm_param_layout;
+
+int cbfssm_param_layout_init(int M, int dim_x, int dim_u, int dim_y, cbfssm_param_layout* out);
+
+/* Positivity transform softplus(x) + 1e-10 of every *_unc tensor (tf_transform.py:19-21); the other tensors are copied.
+ * cflat has the layout of pflat. */
+int cbfssm_constrain_f64(const cbfssm_param_layout* pl, const double* pflat, double* cflat, void* stream);
+
+/* Scratch doubles cbfssm_train_tail_f64 needs. */
+int64_t cbfssm_train_tail_work_elems(const cbfssm_pack_layout* layout_f, const cbfssm_pack_layout* layout_b);
+
+/*
+ * What tf.gradients (base_model.py:34-36) does after the time loops: the adjoint of GPModel.__init__ / prior_kl
+ * (K_mm -> Cholesky -> K^-1, gp_tf.py:33-65,129-130,163-172) for gp_f and gp_b from the reduced adjoint slabs, and the
+ * chain through the positivity transforms.  red = [slab_f | slab_b | loglik, kl_x, entropy, dloss/dvar_y[dim_y]] as
+ * produced by cbfssm_reduce_partials_f64 (summed over the ranks for a multi-GPU step); gB_dense_*: the dense K^-1
+ * adjoints of stash mode (M > 112), NULL otherwise.  Writes d loss / d (flat parameter vector) to gflat.
+ */
+int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layout* layout_f, const double* pack_f,
+                          const cbfssm_pack_layout* layout_b, const double* pack_b, const double* red,
+                          const double* gB_dense_f, const double* gB_dense_b, int64_t gB_ld, const double* pflat,
+                          const double* cflat, double* work, double* gflat, void* stream);
+
+/* tf.train.AdamOptimizer(learning_rate).minimize (cbfssm.py:273-275; TF 1.8 rule): t_dev (one double on the device)
+ * is incremented, then lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), p -= lr_t m / (sqrt(v) + eps). */
+int cbfssm_adam_step_f64(int64_t n, double* pflat, const double* gflat, double* m, double* v, double* t_dev, double lr,
+                         double beta1, double beta2, double eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,31 @@ def test_train_step_decreases_loss_and_matches_tf_adam_rule():
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize('kw', [
+    dict(M=20, T=13, B=2, S=8),
+    dict(M=130, dim_x=9, dim_u=3, dim_y=2, T=14, B=2, S=9, recog_len=3, k_factor=20.),       # stash mode: dense K^-1 adjoint
+])
+def test_hip_train_tail_equals_tensor_library_tail(kw, monkeypatch):
+    """cbfssm_train_tail_f64 (five launches) against the same adjoint written with torch ops (CBFSSM_TORCH_TAIL=1)."""
+    w = syn.tiny(loss_factors=(2., 0.4), **kw)
+    cfg = w.model_config()
+    p = {k: torch.tensor(v, device=DEV) for k, v in syn.perturb_params(syn.make_params(w, seed=3), scale=0.1).items()}
+    u, y = syn.make_inputs(w)
+    noise = syn.make_noise(w)
+    eng = train.HipElboGrad(cfg, DEV)
+    assert eng.fused_tail
+    l1, g1, _ = eng.loss_and_grads(p, u, y, noise)
+    g1 = {k: v.clone() for k, v in g1.items()}
+    monkeypatch.setenv('CBFSSM_TORCH_TAIL', '1')
+    eng2 = train.HipElboGrad(cfg, DEV)
+    assert not eng2.fused_tail
+    l2, g2, _ = eng2.loss_and_grads(p, u, y, noise)
+    assert float(l1) == float(l2)
+    for k in train.PARAM_NAMES:
+        scale = float(g2[k].abs().max()) + 1e-300
+        assert float((g1[k] - g2[k]).abs().max()) <= 1e-11 * scale, k
+
+
 @pytest.mark.parametrize('split', [None, '1'])
 def test_graph_captured_train_step_equals_eager(split, monkeypatch):
     """HipTrainStep replays one captured HIP graph per step (default); the eager path must give the same parameters,
