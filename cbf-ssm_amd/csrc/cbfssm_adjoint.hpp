@@ -440,7 +440,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 }
             }
         }
-        if (has_next) store_inputs(xqn, hnext, auxn);    // xqn was last read in phase G of the previous step
         CBF_STAMP_BARRIER(1);
 
         // ---- C: A2 rows of this wave, P1/P2
@@ -549,6 +548,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             }
         }
         CBF_STAMP_MARK(5);
+        // next step's inputs: loaded at the top of the step, their latency is behind phases B and E by now
+        // (xqn was last read in phase G of the previous step, it is next read after the barrier that ends this step)
+        if (has_next) store_inputs(xqn, hnext, auxn);
         CBF_STAMP_BARRIER(4);
 
         // ---- F: Kbar, Ebar, input adjoint partials, Zbar~

@@ -23,7 +23,7 @@ for _ in range(int(os.environ.get('REPS', '40'))):
     eng.loss_and_grads(params, u, y, noise)
 torch.cuda.synchronize()
 ws = eng.last_ws
-names = ['A fill', 'B ktile', 'C a2,P', 'D epi', 'E a2bar,gB', 'F kbar,xp,gZ', 'G carry']
+names = ['-', 'B ktile (+ next inputs -> LDS)', '-', '-', 'E a2bar,gB', 'F kbar,xp,gZ', 'G carry + D(next)']
 for tag, slab, nwg, nstep_total in (('fwd-adjoint', eng.red[:eng.slab_f], ws.n_f, (w.T - 1)),
                                     ('bwd-adjoint', eng.red[eng.slab_f:eng.slab_f + eng.slab_b], ws.n_b, None)):
     small = slab[-192:].cpu().numpy()
@@ -34,10 +34,10 @@ for tag, slab, nwg, nstep_total in (('fwd-adjoint', eng.red[:eng.slab_f], ws.n_f
         tot = c.sum() + wt.sum()
         print('  %-8s total cycles (sum over WGs) %.4g' % (wname, tot))
         for i in range(7):
-            print('     %-14s compute %5.1f%%  barrier-wait %5.1f%%' % (names[i], 100 * c[i] / tot, 100 * wt[i] / tot))
+            print('     %-32s compute %5.1f%%  barrier-wait %5.1f%%' % (names[i], 100 * c[i] / tot, 100 * wt[i] / tot))
         if wname == 'wave0':
             marks = small[128:137]
-            mn = ['C loop (only without saved A2)', 'A state load -> xq', 'A aux rows', 'A epilogue inputs, A2 issue',
-                  'A/D epilogue adjoint', 'E whole', 'F loop(25)', 'F xp(8)', 'F transpose+gZ(8)']
+            mn = ['C loop (only without saved A2)', '-', '-', 'D epilogue adjoint (next step)', '-', 'E whole',
+                  'F loop(25)', 'F xp(8)', 'F transpose+gZ(8)']
             for i in range(9):
                 print('        sub %-20s %5.1f%%' % (mn[i], 100 * marks[i] / tot))
