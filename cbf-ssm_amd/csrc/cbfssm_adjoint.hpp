@@ -448,23 +448,43 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             d4 acc[RB][2];
 #pragma unroll
             for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
-            int s = 0;
+            if constexpr (BLDS) {
+                int s = 0;
 #pragma unroll 2
-            for (; s + 1 < KSr; s += 2) {
-                const double b0 = Kt[(4 * s + g) * PD + nl], b1 = Kt[(4 * s + 4 + g) * PD + nl];
+                for (; s + 1 < KSr; s += 2) {
+                    const double b0 = Kt[(4 * s + g) * PD + nl], b1 = Kt[(4 * s + 4 + g) * PD + nl];
 #pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    if (ok[i]) {
-                        acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
-                        acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
+                    for (int i = 0; i < RB; ++i) {
+                        if (ok[i]) {
+                            acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                            acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
+                        }
                     }
                 }
-            }
-            if (s < KSr) {
-                const double b0 = Kt[(4 * s + g) * PD + nl];
+                if (s < KSr) {
+                    const double b0 = Kt[(4 * s + g) * PD + nl];
 #pragma unroll
-                for (int i = 0; i < RB; ++i)
-                    if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                    for (int i = 0; i < RB; ++i)
+                        if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                }
+            } else {
+                // K^-1 streams from L2: issue the operand loads of four k-steps together, ahead of their MFMAs (the
+                // image is zero-padded to KS = 4 NBLK k-steps, the tile rows beyond M are finite)
+#pragma unroll 1
+                for (int s0 = 0; s0 < KSr; s0 += 4) {
+                    double b[4], aop[RB][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int i = 0; i < RB; ++i) aop[i][j] = bop[i][(s0 + j) * 64];
+                        b[j] = Kt[(4 * (s0 + j) + g) * PD + nl];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < RB; ++i)
+                            if (ok[i]) acc[i][j & 1] = CBF_MFMA(aop[i][j], b[j], acc[i][j & 1]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) a2[i] = acc[i][0] + acc[i][1];
@@ -562,23 +582,43 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             d4 acc[RB][2];
 #pragma unroll
             for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
-            int s = 0;
+            if constexpr (BLDS) {
+                int s = 0;
 #pragma unroll 2
-            for (; s + 1 < KSr; s += 2) {
-                const double b0 = A2t[(4 * s + g) * PD + nl], b1 = A2t[(4 * s + 4 + g) * PD + nl];
+                for (; s + 1 < KSr; s += 2) {
+                    const double b0 = A2t[(4 * s + g) * PD + nl], b1 = A2t[(4 * s + 4 + g) * PD + nl];
 #pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    if (ok[i]) {
-                        acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
-                        acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
+                    for (int i = 0; i < RB; ++i) {
+                        if (ok[i]) {
+                            acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                            acc[i][1] = CBF_MFMA(bop[i][(s + 1) * 64], b1, acc[i][1]);
+                        }
                     }
                 }
-            }
-            if (s < KSr) {
-                const double b0 = A2t[(4 * s + g) * PD + nl];
+                if (s < KSr) {
+                    const double b0 = A2t[(4 * s + g) * PD + nl];
 #pragma unroll
-                for (int i = 0; i < RB; ++i)
-                    if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                    for (int i = 0; i < RB; ++i)
+                        if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
+                }
+            } else {
+                // K^-1 streams from L2: issue the operand loads of four k-steps together, ahead of their MFMAs (the
+                // image is zero-padded to KS = 4 NBLK k-steps, the tile rows beyond M are finite)
+#pragma unroll 1
+                for (int s0 = 0; s0 < KSr; s0 += 4) {
+                    double b[4], aop[RB][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int i = 0; i < RB; ++i) aop[i][j] = bop[i][(s0 + j) * 64];
+                        b[j] = A2t[(4 * (s0 + j) + g) * PD + nl];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < RB; ++i)
+                            if (ok[i]) acc[i][j & 1] = CBF_MFMA(aop[i][j], b[j], acc[i][j & 1]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i)
