@@ -280,8 +280,9 @@ class HipElboGrad:
     # number of 16-chain groups is not a multiple of the CU count (C3: 320 groups on 256 CUs), the one-workgroup-per-
     # group forward-direction kernels would leave 3/4 of the chip idle in their last round; the remainder groups are
     # run early and the many-workgroup backward-run kernels of the other piece fill the idle CUs meanwhile.
-    def _split(self, prob):
-        if self.stash or os.environ.get('CBFSSM_NO_SPLIT'):
+    def _split(self, prob, adjoint=True):
+        # (the stash-mode adjoint has its own launch schedule; its forward evaluation still splits)
+        if (self.stash and adjoint) or os.environ.get('CBFSSM_NO_SPLIT'):
             return None
         groups = (prob.B * prob.S + 15) // 16
         force = os.environ.get('CBFSSM_SPLIT_MAIN')            # tests: force a split at this group index
@@ -306,7 +307,7 @@ class HipElboGrad:
 
     def _elbo_forward(self, prob, ws, c, u, y, hid_b, eps_b, eps_f):
         lf = self.config['loss_factors']
-        split = self._split(prob)
+        split = self._split(prob, adjoint=False)
         if split is None:
             ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws)
             return

@@ -12,7 +12,7 @@ template <int NBLK>
 struct Cfg {
     // (measured at NBLK = 7, C3: 4 waves x 2 row blocks with K^-1 in VGPRs needs 380 registers -> one wave per SIMD,
     //  2.6x slower; the same with K^-1 streamed from L2 fits two workgroups per CU but is 10-20 % slower than this)
-    static constexpr int RB = (NBLK > 16) ? 2 : 1;
+    static constexpr int RB = (NBLK >= 13) ? 2 : 1;
     static constexpr bool BREG = (NBLK <= 7);
 };
 
