@@ -140,3 +140,33 @@ def test_elbo_forward_matches_oracle(kw):
     x1 = ws.x.clone()
     ws = eng.run(u, y, noise, condition=True)
     assert torch.equal(out1, ws.out) and torch.equal(x1, ws.x)
+
+
+@pytest.mark.parametrize('kw', [
+    dict(M=200, dim_x=14, dim_u=7, dim_y=7, T=9, B=1, S=20, recog_len=2, k_factor=50.),      # 2 column blocks, 2nd ragged
+    dict(M=250, dim_x=4, dim_u=2, dim_y=2, T=9, B=3, S=11, recog_len=3, k_factor=1.),        # 3 blocks: odd count
+])
+def test_shared_operand_pass_variant_matches_oracle(kw, monkeypatch):
+    """Tile heights 13..16: pass_kernel<NC = 2> (two column blocks share every streamed K^-1 operand load; the default
+    from N = 4096 chains on) forced on small cases, against the oracle, and the adjoint fed by its saved A2 tiles."""
+    from cbfssm.hip import train
+    from oracle import cbfssm_torch_ref as tref
+    monkeypatch.setenv('CBFSSM_NC_FWD', '3')
+    monkeypatch.setenv('CBFSSM_NC_BWD', '3')
+    orc = _oracle()
+    w = syn.tiny(loss_factors=(2., 0.4), **kw)
+    cfg = w.model_config()
+    p = syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)
+    u, y = syn.make_inputs(w, seed=0)
+    noise = syn.make_noise(w, seed=2)
+    ref = orc.elbo_step(cfg, p, u, y, noise, True)
+    eng = ops.HipElbo(cfg, DEV)
+    eng.prepare(p)
+    ws = eng.run(u, y, noise, condition=True)
+    _compare(ws, w, ref)
+    g = train.HipElboGrad(cfg, DEV)
+    loss, grads, _ = g.loss_and_grads({k: torch.tensor(v, device=DEV) for k, v in p.items()}, u, y, noise)
+    scal, gref = tref.loss_and_grads(cfg, p, u, y, noise, True)
+    assert abs(float(loss) - scal['loss']) <= 1e-9 * abs(scal['loss'])
+    for k in train.PARAM_NAMES:
+        np.testing.assert_allclose(grads[k].cpu().numpy(), gref[k], rtol=1e-6, atol=1e-7 * np.abs(gref[k]).max())
