@@ -21,7 +21,7 @@ SYMBOLS = (
     'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64', 'cbfssm_bwd_segments', 'cbfssm_forward_pass_bwd_ex_f64',
     'cbfssm_backward_pass_bwd_ex_f64', 'cbfssm_half_forward_pass_f64', 'cbfssm_half_forward_pass_bwd_f64',
     'cbfssm_saved_a2_elems', 'cbfssm_param_layout_init', 'cbfssm_constrain_f64', 'cbfssm_train_tail_work_elems',
-    'cbfssm_train_tail_f64', 'cbfssm_adam_step_f64',
+    'cbfssm_train_tail_f64', 'cbfssm_adam_step_f64', 'cbfssm_loglik_partials',
 )
 
 
@@ -73,6 +73,8 @@ def load():
     lib.cbfssm_backward_pass_partials.argtypes = [C.POINTER(Problem)]
     lib.cbfssm_backward_pass_f64.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 12
     lib.cbfssm_forward_pass_partials.restype = i64
+    lib.cbfssm_loglik_partials.restype = i64
+    lib.cbfssm_loglik_partials.argtypes = [C.POINTER(Problem)]
     lib.cbfssm_param_layout_init.argtypes = [ip, ip, ip, ip, C.POINTER(ParamLayout)]
     lib.cbfssm_constrain_f64.argtypes = [C.POINTER(ParamLayout), vp, vp, vp]
     lib.cbfssm_train_tail_work_elems.restype = i64

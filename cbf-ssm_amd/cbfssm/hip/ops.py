@@ -146,7 +146,7 @@ class ElboWorkspace:
         self.x = torch.zeros(T, N, p.dim_x, **f)
         self.ent_part = torch.zeros(self.n_ent, **f)
         self.kl_part = torch.zeros(self.n_kl, **f)
-        self.ll_part = torch.zeros(p.B * T * p.dim_y, **f)
+        self.ll_part = torch.zeros(int(lib.cbfssm_loglik_partials(C.byref(p))), **f)   # [block][dim_y]
         self.pred_mean = torch.zeros(p.B, T, p.dim_y, **f)
         self.pred_var = torch.zeros(p.B, T, p.dim_y, **f)
         self.int_mean = torch.zeros(p.B, T, p.dim_x, **f)

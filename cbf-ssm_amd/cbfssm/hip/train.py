@@ -228,7 +228,7 @@ class HipElboGrad:
             gB_f, gB_b = self._adjoint_stash(prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red)
         # ---- data scalars and the log-likelihood's pull on var_y (cbfssm.py:245-251)
         vy = c['var_y'][:self.dim_y]
-        ll_d = ws.ll_part.view(B * T, self.dim_y).sum(0)
+        ll_d = ws.ll_part.view(-1, self.dim_y).sum(0)
         sq_d = (-2.0 * ll_d - B * T * self.S * (LOG2PI + torch.log(vy))) * vy
         gvy_ll = -cL * 0.5 * (sq_d / (vy * vy) - B * T * self.S / vy)
         tail = red[sf + sb:]

@@ -170,7 +170,7 @@ class HipHalfGrad:
             keep = 8.0 * n_a2 <= float(os.environ.get('CBFSSM_A2S_MAX_GB', '24')) * 2 ** 30
             ws.a2s_f = torch.zeros(max(n_a2, 1), **f) if keep else None
             ws.kl_part = torch.zeros(ws.n_kl, **f)
-            ws.ll_part = torch.zeros(prob.B * prob.T * prob.dim_y, **f)
+            ws.ll_part = torch.zeros(int(lib.cbfssm_loglik_partials(C.byref(prob))), **f)   # [block][dim_y]
             ws.pred_mean = torch.zeros(prob.B, prob.T, prob.dim_y, **f)
             ws.pred_var = torch.zeros(prob.B, prob.T, prob.dim_y, **f)
             ws.int_mean = torch.zeros(prob.B, prob.T, prob.dim_x, **f)
@@ -282,7 +282,7 @@ class HipHalfGrad:
 
         # log-likelihood's pull on var_y (cbfssmhalf.py:181-189)
         vy = c['var_y']
-        ll_d = ws.ll_part.view(B * T, self.dim_y).sum(0)
+        ll_d = ws.ll_part.view(-1, self.dim_y).sum(0)
         sq_d = (-2.0 * ll_d - B * T * self.S * (LOG2PI + torch.log(vy))) * vy
         tail = red[sf:]
         tail[0:2] = ws.out[0:2]

@@ -266,9 +266,12 @@ struct LlArgs {
 
 __global__ void loglik_moments_kernel(LlArgs a)
 {
+    // per-block, per-dimension partial sums of the log-likelihood (fixed order): ll_part[block][dim_y]
+    __shared__ double sh[256];
     const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t total = int64_t(a.B) * a.T * a.dim_x;
-    if (idx >= total) return;
+    double ll = 0.0;
+    if (idx < total) {
     const int d = int(idx % a.dim_x);
     const int64_t bt = idx / a.dim_x;
     const int t = int(bt % a.T), b = int(bt / a.T);
@@ -293,7 +296,17 @@ __global__ void loglik_moments_kernel(LlArgs a)
         const double yo = a.y[o];
         const double dm = yo - mean;
         const double sq = ss + a.S * dm * dm;
-        a.ll_part[o] = -0.5 * (sq / vy + a.S * (1.8378770664093454836 + log(vy)));
+        ll = -0.5 * (sq / vy + a.S * (1.8378770664093454836 + log(vy)));
+    }
+    }
+    sh[threadIdx.x] = ll;
+    __syncthreads();
+    if (int(threadIdx.x) < a.dim_y) {
+        const int d = threadIdx.x;
+        const int base = int((int64_t(blockIdx.x) * 256) % a.dim_x);
+        double s = 0.0;
+        for (int k = (d - base + a.dim_x) % a.dim_x; k < 256; k += a.dim_x) s += sh[k];
+        a.ll_part[int64_t(blockIdx.x) * a.dim_y + d] = s;
     }
 }
 
@@ -711,6 +724,12 @@ int cbfssm_loglik_moments_f64(const cbfssm_problem* p, const double* var_y, cons
     hipLaunchKernelGGL(loglik_moments_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, a);
     return check_launch("loglik_moments");
+}
+
+int64_t cbfssm_loglik_partials(const cbfssm_problem* p)
+{
+    if (!p) return -1;
+    return (int64_t(p->B) * p->T * p->dim_x + 255) / 256 * p->dim_y;
 }
 
 int cbfssm_elbo_combine_f64(const cbfssm_problem* p, double lambda0, double lambda1, const double* ll_part,

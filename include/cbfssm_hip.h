@@ -171,9 +171,12 @@ int cbfssm_half_forward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_
  * Log-likelihood and predictive moments, CBFSSM._build_loss (cbfssm.py:245-251) and _build_prediction
  * (cbfssm.py:264-269).
  *   x (T,N,dim_x), y (B,T,dim_y), var_y (dim_x)
- *   -> ll_part (B*T doubles: log-lik summed over particles per (b,t)), pred_mean (B,T,dim_y), pred_var (B,T,dim_y),
+ *   -> ll_part (cbfssm_loglik_partials(problem) doubles, laid out [block][dim_y]: per-workgroup, per-dimension partial
+ *      sums of the log-likelihood in a fixed order; their total is `loglik`, their per-dimension totals drive the
+ *      gradient with respect to var_y), pred_mean (B,T,dim_y), pred_var (B,T,dim_y),
  *      int_mean (B,T,dim_x) / int_var (B,T,dim_x) or NULL.
  */
+int64_t cbfssm_loglik_partials(const cbfssm_problem* p);
 int cbfssm_loglik_moments_f64(const cbfssm_problem* p, const double* var_y, const double* y, const double* x,
                               double* ll_part, double* pred_mean, double* pred_var, double* int_mean,
                               double* int_var, void* stream);
