@@ -75,6 +75,7 @@ struct PrepArgs2 {
 };
 
 #define PREP_NT 1024
+#define PREP_NB 32
 #define PREP_LDS_MAX_M 140   // (M | 1) * M doubles must fit the 160 KiB LDS next to the small arrays
 
 // One workgroup per GPModel (blockIdx.x).  The working matrix W (row stride LD, odd) starts as
@@ -110,39 +111,143 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
     }
     __syncthreads();
     const double var = a.var[0];
-    for (int i = ty; i < M; i += 32) {
-        for (int k = tx; k < M; k += 32) {
-            double dot = 0.0;
-            for (int j = 0; j < D; ++j) dot += a.Zs[i * D + j] * a.Zs[k * D + j];
-            const double d2 = -2.0 * dot + Xs[i] + Xs[k];                 // gp_tf.py:37-38, no clamp
-            const double kv = var * exp(-0.5 * d2);                       // gp_tf.py:49
-            a.Kmm[i * M + k] = kv;
-            Wm[i * LD + k] = (k < i) ? kv : ((k == i) ? kv + a.jitter : 0.0);   // gp_tf.py:53
+    constexpr int NWAVE = PREP_NT / 64;
+    const int NBT = (M + 15) / 16;
+    const int wv = tid >> 6, l = tid & 63, g = l >> 4, nl = l & 15;
+    // X X^T in 16 x 16 tiles on the f64 MFMA units (gp_tf.py:36: the matmul of the -2 X X^T + |x|^2 + |x'|^2 expansion)
+    for (int t = wv; t < NBT * NBT; t += NWAVE) {
+        const int ib = t / NBT, kb = t - ib * NBT;
+        const int ia = 16 * ib + nl, ka = 16 * kb + nl;
+        d4 dot = {0, 0, 0, 0};
+        for (int s = 0; 4 * s < D; ++s) {
+            const int j = 4 * s + g;
+            const double av = (ia < M && j < D) ? a.Zs[ia * D + j] : 0.0;
+            const double bv = (ka < M && j < D) ? a.Zs[ka * D + j] : 0.0;
+            dot = CBF_MFMA(av, bv, dot);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ib + g + 4 * r, k = 16 * kb + nl;
+            if (i < M && k < M) {
+                const double d2 = -2.0 * dot[r] + Xs[i] + Xs[k];              // gp_tf.py:37-38, no clamp
+                const double kv = var * exp(-0.5 * d2);                       // gp_tf.py:49
+                a.Kmm[i * M + k] = kv;
+                Wm[i * LD + k] = (k < i) ? kv : ((k == i) ? kv + a.jitter : 0.0);   // gp_tf.py:53
+            }
         }
     }
     __syncthreads();
 
-    double logdet = 0.0;
-    for (int j = 0; j < M; ++j) {
-        const double p = Wm[j * LD + j];
-        if (tid == 0) {
-            piv[j] = p;
-            if (!(p > 0.0) && s_info == 0) s_info = j + 1;
-            logdet += log(p);
+    // Bordered elimination of [[K + jitter I, I], [I, .]] in the one M x M working matrix: the lower triangle ends up as
+    // L diag(piv)^1/2 (column j scaled), the strict upper triangle as the rows of L^-T (same scaling).  Step j subtracts
+    // c_ij W[k][j] from W[i][k], k > j, with c_ij = W[i][j] / p_j (rows i != j; lower rows only up to k <= i) and
+    // c_jj = 1 / p_j (the border row born at step j).  Blocked right-looking form: panels of PREP_NB columns are
+    // eliminated in LDS (all M rows x PREP_NB columns), then ONE rank-PREP_NB update W -= C P^T of everything to the
+    // right of the panel runs on the f64 MFMA units -- M / PREP_NB passes over the matrix instead of M.
+    constexpr int NB = PREP_NB, PL = PREP_NB + 1;
+    double* P = nullptr;
+    if constexpr (!LDSW) P = smem;                       // [16 ceil(M/16)][PL] panel copy (W itself lives in global memory)
+#ifdef CBF_PREP_STAMPS
+    long long tk0 = clock64(), tk_pan = 0, tk_upd = 0;
+#endif
+    for (int j0 = 0; j0 < M; j0 += NB) {
+#ifdef CBF_PREP_STAMPS
+        long long tp0 = clock64();
+#endif
+        const int nb = min(NB, M - j0), j1 = j0 + nb;
+        auto pan = [&](int i, int jj) -> double& {
+            if constexpr (LDSW) return Wm[i * LD + j0 + jj];
+            else return P[i * PL + jj];
+        };
+        if constexpr (!LDSW) {
+            for (int idx = tid; idx < 16 * NBT * NB; idx += PREP_NT) {
+                const int i = idx / NB, jj = idx - i * NB;
+                P[i * PL + jj] = (i < M && jj < nb) ? Wm[i * LD + j0 + jj] : 0.0;
+            }
+            __syncthreads();
         }
-        const double rp = 1.0 / p;
-        // trailing update of the K part (lower triangle incl. diagonal, rows/cols > j)
-        for (int i = j + 1 + ty; i < M; i += 32) {
-            const double aij = Wm[i * LD + j] * rp;
-            for (int k = j + 1 + tx; k <= i; k += 32) Wm[i * LD + k] -= aij * Wm[k * LD + j];
+        // ---- panel: the unblocked steps restricted to the panel's columns
+        for (int jj = 0; jj < nb; ++jj) {
+            const int j = j0 + jj;
+            const double p = pan(j, jj);
+            if (tid == 0) {
+                piv[j] = p;
+                if (!(p > 0.0) && s_info == 0) s_info = j + 1;
+            }
+            const double rp = 1.0 / p;
+            {
+                const int kk = jj + 1 + tx, k = j0 + kk;     // 32 x 32 thread tile: tx -> panel column, ty -> row
+                if (kk < nb) {
+                    const double wkj = rp * pan(k, jj);
+                    for (int i = ty; i < M; i += 32) {
+                        if (i > j && k > i) continue;        // a lower row is updated up to its diagonal only
+                        const double c = (i == j) ? 1.0 : pan(i, jj);
+                        pan(i, kk) -= c * wkj;
+                    }
+                }
+            }
+            __syncthreads();
         }
-        // border rows i <= j of L^-T (strict upper part; entry (j, j) is the implied 1)
-        for (int i = ty; i <= j; i += 32) {
-            const double gij = ((i < j) ? Wm[i * LD + j] : 1.0) * rp;
-            for (int k = j + 1 + tx; k < M; k += 32) Wm[i * LD + k] -= gij * Wm[k * LD + j];
+        if constexpr (!LDSW) {
+            for (int idx = tid; idx < M * nb; idx += PREP_NT) {
+                const int i = idx / nb, jj = idx - i * nb;
+                Wm[i * LD + j0 + jj] = P[i * PL + jj];
+            }
+        }
+#ifdef CBF_PREP_STAMPS
+        __syncthreads();
+        tk_pan += clock64() - tp0;
+        tp0 = clock64();
+#endif
+        if (j1 >= M) break;
+        // ---- rank-nb update of the columns k >= j1 (nb == NB here; 16 | j1): W[i][k] -= sum_jj C[i][jj] W[k][j0+jj]
+        int cnt = 0;
+        for (int ib = 0; ib < NBT; ++ib) {
+            const int i0 = 16 * ib;
+            const int kb_lo = j1 >> 4, kb_hi = (i0 < j1) ? NBT - 1 : ib;
+            for (int kb = kb_lo; kb <= kb_hi; ++kb, ++cnt) {
+                if ((cnt % NWAVE) != wv) continue;
+                const int k0 = 16 * kb;
+                d4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + g + 4 * r, k = k0 + nl;
+                    acc[r] = (i < M && k < M) ? Wm[i * LD + k] : 0.0;
+                }
+                const int ia = i0 + nl;                  // A-operand row of this lane
+                const int kbr = k0 + nl;                 // B-operand column (= row of W) of this lane
+#pragma unroll
+                for (int s = 0; s < NB / 4; ++s) {
+                    const int jj = 4 * s + g;
+                    double av = 0.0;
+                    if (ia < M) {
+                        const double rp = 1.0 / piv[j0 + jj];
+                        if (ia < j0 || ia >= j1) av = pan(ia, jj) * rp;
+                        else if (jj > ia - j0) av = pan(ia, jj) * rp;
+                        else if (jj == ia - j0) av = rp;
+                    }
+                    const double bv = (kbr < M) ? pan(kbr, jj) : 0.0;
+                    acc = CBF_MFMA(-av, bv, acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + g + 4 * r, k = k0 + nl;
+                    if (i < M && k < M && (i < j1 || k <= i)) Wm[i * LD + k] = acc[r];
+                }
+            }
         }
         __syncthreads();
+#ifdef CBF_PREP_STAMPS
+        tk_upd += clock64() - tp0;
+#endif
     }
+#ifdef CBF_PREP_STAMPS
+    long long tk1 = clock64();
+#endif
+    // log det(K + jitter I) = sum_j log piv_j (fixed-order block sum)
+    double ld_part = 0.0;
+    for (int j = tid; j < M; j += PREP_NT) ld_part += log(piv[j]);
+    const double logdet = block_sum(ld_part, red, tid, PREP_NT);
     // outputs: L = W_lower diag(piv)^-1/2, L^-T = W_upper diag(piv)^-1/2 (diagonal 1/sqrt(piv))
     for (int i = ty; i < M; i += 32) {
         for (int k = tx; k < M; k += 32) {
@@ -163,15 +268,38 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
             Wm[i * LD + k] = (k > i) ? Wm[i * LD + k] / sp : 1.0 / sp;    // diagonal now holds G[i][i]
         }
     __syncthreads();
-    for (int i = ty; i < M; i += 32) {
-        for (int k = tx; k <= i; k += 32) {
-            double sum = 0.0;
-            for (int q = i; q < M; ++q) sum += Wm[i * LD + q] * Wm[k * LD + q];   // q >= max(i,k) = i
-            a.Kinv[i * M + k] = sum;
-            a.Kinv[k * M + i] = sum;
+    // K^-1[i][k] = sum_{q >= max(i,k)} G[i][q] G[k][q]: 16 x 16 tiles of the lower triangle on the f64 MFMA units
+    {
+        int cnt = 0;
+        for (int ib = 0; ib < NBT; ++ib) {
+            for (int kb = 0; kb <= ib; ++kb, ++cnt) {
+                if ((cnt % NWAVE) != wv) continue;
+                const int ia = 16 * ib + nl, kr = 16 * kb + nl;
+                d4 acc = {0, 0, 0, 0};
+                for (int qb = ib; qb < NBT; ++qb) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int q = 16 * qb + 4 * s + g;
+                        const double av = (ia < M && q < M && q >= ia) ? Wm[ia * LD + q] : 0.0;
+                        const double bv = (kr < M && q < M && q >= kr) ? Wm[kr * LD + q] : 0.0;
+                        acc = CBF_MFMA(av, bv, acc);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * ib + g + 4 * r, k = 16 * kb + nl;
+                    if (i < M && k < M) {
+                        a.Kinv[i * M + k] = acc[r];
+                        if (ib != kb) a.Kinv[k * M + i] = acc[r];      // (a diagonal tile holds both of its halves)
+                    }
+                }
+            }
         }
     }
     __syncthreads();
+#ifdef CBF_PREP_STAMPS
+    long long tk2 = clock64();
+#endif
     if (!a.Bp) return;
     const double* Cm = a.Kinv;
 
@@ -214,13 +342,21 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
     }
 
     // ---- prior KL: 0.5 sum_d [ tr(K^-1 S_d) + mu_d^T K^-1 mu_d - M + log det K - log det S_d ]   (gp_tf.py:163-172)
+    // K^-1 mu_d for all d at once from the operand images just written: rows of row block rb = sum over the k-steps of
+    // (K^-1 A-operand image) x (zeta_mean B-operand image), one wave per row block
+    __syncthreads();
     double acc = 0.0;
-    for (int i = tid; i < M * Do; i += PREP_NT) {
-        const int m = i / Do, d = i % Do;
-        double kmu = 0.0;
-        for (int k = 0; k < M; ++k) kmu += Cm[m * M + k] * a.zmean[k * Do + d];
-        const double s2 = a.zvar[m * Do + d];
-        acc += Cm[m * M + m] * s2 + a.zmean[m * Do + d] * kmu - log(s2);
+    for (int rb = wv; rb < NBLK; rb += NWAVE) {
+        d4 km = {0, 0, 0, 0};
+        for (int s = 0; s < KS; ++s) km = CBF_MFMA(a.Bp[(rb * KS + s) * 64 + l], a.muA[s * 64 + l], km);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * rb + g + 4 * r, d = nl;           // C-layout: row (lane >> 4) + 4 r, column lane & 15
+            if (m < M && d < Do) {
+                const double s2 = a.zvar[m * Do + d];
+                acc += Cm[m * M + m] * s2 + a.zmean[m * Do + d] * km[r] - log(s2);
+            }
+        }
     }
     const double tot = block_sum(acc, red, tid, PREP_NT);
     if (tid == 0) {
@@ -229,6 +365,10 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
         a.scal[CBFSSM_SCAL_KLZ] = 0.5 * (tot + double(Do) * (logdet - double(M)));
         a.scal[CBFSSM_SCAL_INFO] = double(s_info);
         for (int i = 4; i < CBFSSM_SCAL_COUNT; ++i) a.scal[i] = 0.0;
+#ifdef CBF_PREP_STAMPS
+        a.scal[4] = double(tk_pan); a.scal[5] = double(tk_upd); a.scal[6] = double(tk2 - tk1); a.scal[7] = double(clock64() - tk2);
+        // (scal[4..7]: cycles in panels, rank updates, outputs + K^-1 = G G^T, operand images + KL; Kmm build = rest)
+#endif
     }
 }
 
@@ -244,7 +384,13 @@ static int launch_prepare(PrepArgs2& aa, int n, int maxM, hipStream_t st)
         }
         hipLaunchKernelGGL(prepare_kernel<true>, dim3(n), dim3(PREP_NT), lds, st, aa);
     } else {
-        hipLaunchKernelGGL(prepare_kernel<false>, dim3(n), dim3(PREP_NT), 0, st, aa);
+        const size_t pl = size_t(16 * ((maxM + 15) / 16)) * (PREP_NB + 1) * sizeof(double);   // panel copy
+        if (pl > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prepare_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(pl));
+            if (e != hipSuccess) return fail(-int(e) - 1000, "prepare: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(prepare_kernel<false>, dim3(n), dim3(PREP_NT), pl, st, aa);
     }
     return check_launch("gp_prepare");
 }
