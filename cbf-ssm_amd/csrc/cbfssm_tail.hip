@@ -21,7 +21,7 @@ struct GpTail {
     const double* Kinv;       // [M][M]
     const double* Kmm;        // [M][M]
     const double* Zs;         // [M][D]   z / lengthscale
-    double* T;                // scratch [M][max(M,32)]
+    double* T;                // scratch [M][max(M,48)]: Kinv G, then WZ [M][D] and K^-1 mu [M][Do]
     double* G2;               // scratch [M][M]
     const double* zmean;      // [M][Do]
     const double* zvar;       // [M][Do]  constrained
@@ -82,6 +82,8 @@ __device__ __forceinline__ double g_elem(const GpTail& p, int k, int j)
 }
 
 // STAGE 0: T = Kinv G.   STAGE 1: G2 = (-T Kinv + 0.5 Do Kinv) o Kmm   (K^-1 = (K_mm + jitter I)^-1, log det of the KL)
+// STAGE 2 (column tiles 0,1: Ws Z~ with Ws = -0.5 (G2 + G2^T); column tile 2: K^-1 zeta_mean), results behind each other
+// in the T scratch: WZ [M][D], KM [M][Do]
 template <int STAGE>
 __global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
 {
@@ -90,7 +92,35 @@ __global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
     __shared__ double As[16][17], Bs[16][17];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
-    if (int(blockIdx.y) * 16 >= M || int(blockIdx.x) * 16 >= M) return;
+    if (int(blockIdx.y) * 16 >= M) return;
+    if constexpr (STAGE == 2) {
+        const bool km = (blockIdx.x == 2);
+        const int jc = km ? tx : j;                       // output column inside WZ / KM
+        const int ncol = km ? p.Do : p.D;
+        if (!km && int(blockIdx.x) * 16 >= p.D) return;
+        double acc = 0.0;
+        for (int k0 = 0; k0 < M; k0 += 16) {
+            double av = 0.0;
+            if (i < M && k0 + tx < M) {
+                const int k = k0 + tx;
+                av = km ? p.Kinv[int64_t(i) * M + k] : -0.5 * (p.G2[int64_t(i) * M + k] + p.G2[int64_t(k) * M + i]);
+            }
+            As[ty][tx] = av;
+            double bv = 0.0;
+            if (k0 + ty < M && jc < ncol) bv = km ? p.zmean[(k0 + ty) * p.Do + jc] : p.Zs[(k0 + ty) * p.D + jc];
+            Bs[ty][tx] = bv;
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = fma(As[ty][kk], Bs[kk][tx], acc);
+            __syncthreads();
+        }
+        if (i < M && jc < ncol) {
+            if (km) p.T[int64_t(M) * p.D + i * p.Do + jc] = acc;
+            else p.T[i * p.D + jc] = acc;
+        }
+        return;
+    }
+    if (int(blockIdx.x) * 16 >= M) return;
     const double* A = (STAGE == 0) ? p.Kinv : p.T;
     double acc = 0.0;
     for (int k0 = 0; k0 < M; k0 += 16) {
@@ -120,7 +150,6 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
     const int tid = threadIdx.x, NT = 256;
     __shared__ double wsrow[320];
     __shared__ double red[8];
-    __shared__ double col[32];
     const double* gMu = p.slab;
     const double* gS2 = p.slab + NBLK * 256;
     const double* gZ = p.slab + 2 * NBLK * 256 + (p.stash ? 0 : NBLK * NBLK * 256);
@@ -128,41 +157,37 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
     const double* G2 = p.G2;
 
     // K = var exp(-0.5 d2(z~)): Kbar o K = G2;  Wd = -0.5 G2, Ws = Wd + Wd^T                           (gp_tf.py:33-49)
+    const double* WZ = p.T;                              // Ws z~   [M][D]     (tail_gemm<2>)
+    const double* KM = p.T + int64_t(M) * D;             // K^-1 mu [M][Do]
+    const int wv = tid >> 6, l = tid & 63;
     double tot = 0.0;
-    for (int i = tid; i < M; i += NT) {
-        double s = 0.0;
-        for (int j = 0; j < M; ++j) {
+    for (int i = wv; i < M; i += NT / 64) {              // one wave per row: lanes over the columns
+        double s = 0.0, t1 = 0.0;
+        for (int j = l; j < M; j += 64) {
             const double gij = G2[int64_t(i) * M + j];
             s += gij + G2[int64_t(j) * M + i];
-            tot += gij;
+            t1 += gij;
         }
-        wsrow[i] = -0.5 * s;
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); t1 += __shfl_xor(t1, o); }
+        if (l == 0) { wsrow[i] = -0.5 * s; tot += t1; }
     }
     tot = block_sum_t(tot, red, tid, NT);
     __syncthreads();
 
     // Z~bar = Ebar x~^T - z~ o rowsum(Ebar) + 2 (rowsum(Ws) o z~ - Ws z~);   zbar = Z~bar / ls
-    double* gzs = p.T;                      // [M][D]: Z~bar o z~, for the lengthscale column sums
+    // lengthscales: -(colsum(Z~bar o z~) + inputs' part) / ls; thread j < D walks its column (fixed order)
     for (int idx = tid; idx < M * D; idx += NT) {
         const int i = idx / D, j = idx - i * D;
-        double wz = 0.0;
-        for (int k = 0; k < M; ++k) wz = fma(G2[int64_t(i) * M + k] + G2[int64_t(k) * M + i], p.Zs[k * D + j], wz);
-        wz *= -0.5;
-        const double zs = p.Zs[i * D + j];
-        const double gzt = c_image(gZ, JB, i, j) - zs * c_image(gZ, JB, i, D) + 2.0 * (wsrow[i] * zs - wz);
+        const double zs = p.Zs[idx];
+        const double gzt = c_image(gZ, JB, i, j) - zs * c_image(gZ, JB, i, D) + 2.0 * (wsrow[i] * zs - WZ[idx]);
         p.g_z[idx] = gzt / p.ls[j];
-        gzs[idx] = gzt * zs;
     }
     __syncthreads();
     if (tid < D) {
+        const int j = tid;
         double s = 0.0;
-        for (int i = 0; i < M; ++i) s += gzs[i * D + tid];
-        col[tid] = s;
-    }
-    __syncthreads();
-    if (tid < D) {
-        const double glx = small[32 + tid];
-        p.g_ls[tid] = -(col[tid] + glx) / p.ls[tid] * sigmoid(p.ls_unc[tid]);
+        for (int i = 0; i < M; ++i) s += p.g_z[i * D + j] * p.Zs[i * D + j];      // = Z~bar o z~ / ls
+        p.g_ls[j] = -(s + small[32 + j] / p.ls[j]) * sigmoid(p.ls_unc[j]);
     }
     if (tid == 0) {
         const double var = p.var[0];
@@ -171,9 +196,7 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
     // inducing mean / variance: data part from the slab + prior KL                                    (gp_tf.py:163-172)
     for (int idx = tid; idx < M * Do; idx += NT) {
         const int i = idx / Do, d = idx - i * Do;
-        double km = 0.0;
-        for (int k = 0; k < M; ++k) km = fma(p.Kinv[int64_t(i) * M + k], p.zmean[k * Do + d], km);
-        p.g_mu[idx] = c_image(gMu, 1, i, d) + km;
+        p.g_mu[idx] = c_image(gMu, 1, i, d) + KM[idx];
         const double gs2 = c_image(gS2, 1, i, d) + 0.5 * (p.Kinv[int64_t(i) * M + i] - 1.0 / p.zvar[idx]);
         p.g_s2[idx] = gs2 * sigmoid(p.zvar_unc[idx]);
     }
@@ -273,7 +296,7 @@ int cbfssm_constrain_f64(const cbfssm_param_layout* pl, const double* pflat, dou
 int64_t cbfssm_train_tail_work_elems(const cbfssm_pack_layout* Lf, const cbfssm_pack_layout* Lb)
 {
     if (!Lf || !Lb) return -1;
-    auto one = [](const cbfssm_pack_layout* L) { return int64_t(L->M) * (L->M > 32 ? L->M : 32) + int64_t(L->M) * L->M; };
+    auto one = [](const cbfssm_pack_layout* L) { return int64_t(L->M) * (L->M > 48 ? L->M : 48) + int64_t(L->M) * L->M; };
     return one(Lf) + one(Lb);
 }
 
@@ -303,7 +326,7 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
         p.slab = slab; slab += L[g]->rev_slab;
         p.gB_dense = gBd[g]; p.gB_ld = gB_ld;
         p.Kinv = pack[g] + L[g]->Kinv; p.Kmm = pack[g] + L[g]->Kmm; p.Zs = pack[g] + L[g]->Zs;
-        p.T = w; w += int64_t(M) * (M > 32 ? M : 32);
+        p.T = w; w += int64_t(M) * (M > 48 ? M : 48);
         p.G2 = w; w += int64_t(M) * M;
         const int64_t* off = pl->off + 5 * g;
         p.zmean = cflat + off[1]; p.zvar = cflat + off[2]; p.var = cflat + off[3]; p.ls = cflat + off[4];
@@ -320,6 +343,7 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tail_gemm<0>, dim3(nb, nb, 2), dim3(16, 16), 0, st, a);
     hipLaunchKernelGGL(tail_gemm<1>, dim3(nb, nb, 2), dim3(16, 16), 0, st, a);
+    hipLaunchKernelGGL(tail_gemm<2>, dim3(3, nb, 2), dim3(16, 16), 0, st, a);
     hipLaunchKernelGGL(tail_finish, dim3(2), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-int(e) - 1000, "train tail launch failed");

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Everything DESIGN.md section 6 quotes, in one GPU-box call (run from the repo root):
+#   bash profiles/tools/collect_round_profile.sh gpurun_out/final
+# -> bench lines (C3 train/eval with CPU baseline, C1/C2/C4 train), rocprofv3 kernel stats of the C3 train step,
+#    PMC traffic of the C3 kernels.  Copy what should be judged into profiles/<round>/.
+set -e
+OUT=${1:-gpurun_out/final}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/$OUT
+cd $R
+bash profiles/tools/collect_traffic.sh C3 $OUT/traffic
+mkdir -p profiles/r01 && cp $OUT/traffic.traffic.json profiles/r01/traffic.json   # bench.py reads it below
+python3 bench.py > $OUT/bench_train_C3.json 2> $OUT/bench_train_C3.err
+python3 bench.py --mode eval > $OUT/bench_eval_C3.json 2> $OUT/bench_eval_C3.err
+for w in C1 C2 C4; do python3 bench.py --workload $w --mode train --no-cpu-baseline > $OUT/bench_train_$w.json 2> $OUT/bench_train_$w.err; done
+cd /tmp && export TMPDIR=/tmp
+CBFSSM_HIP_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ktrace -o c3 -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/$OUT/ktrace.log 2>&1
+cp $(ls $R/$OUT/ktrace/*kernel_stats.csv | head -1) $R/$OUT/train_C3_kernel_stats.csv
+ls -la $R/$OUT

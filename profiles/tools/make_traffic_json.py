@@ -1,0 +1,48 @@
+"""HBM bytes per launch of the four time-loop kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB),
+written as profiles/<round>/traffic.json (bench.py reads it into roofline.traffic).
+usage: make_traffic_json.py <workload> <fetch_dir> <write_dir> <out.json>"""
+import csv, glob, json, re, sys, collections
+
+wl, fdir, wdir, out = sys.argv[1:5]
+
+
+def kind(name):
+    m = re.search(r'(rev_kernel|pass_kernel_skew|pass_kernel)<([^>]*)>', name)
+    if not m:
+        return None
+    args = [x.strip() for x in m.group(2).split(',')]
+    fam = m.group(1)
+    mode = int(args[5] if fam == 'rev_kernel' else args[4])
+    base = 'backward_pass' if mode == 1 else 'forward_pass'
+    return base + ('_adjoint' if fam == 'rev_kernel' else '')
+
+
+def collect(path, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(path + '/**/*counter_collection.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row['Counter_Name'] != counter:
+                continue
+            k = kind(row['Kernel_Name'])
+            if k:
+                acc[k].append(float(row['Counter_Value']))
+    return acc
+
+
+fe, wr = collect(fdir, 'FETCH_SIZE'), collect(wdir, 'WRITE_SIZE')
+res = {}
+for k in sorted(fe):
+    # the largest dispatches are the full launches (bench.py's per-kernel timing); the smaller ones are the pieces of the
+    # chain-group split inside a whole step
+    f, w = max(fe[k]), max(wr.get(k, [0.0]))
+    res[k] = int((f + w) * 1024)
+    print('%-24s fetch %.1f MB  write %.1f MB  (%d dispatches)' % (k, f * 1024 / 1e6, w * 1024 / 1e6, len(fe[k])))
+res['_note'] = ('bytes per full launch = (FETCH_SIZE + WRITE_SIZE) KiB x 1024 from separate rocprofv3 --pmc passes of '
+                '`bench.py --workload %s --steps 1 --warmup 1` (profiles/tools/collect_traffic.sh); no x2 correction: '
+                'the kernels load 8 B per lane (calibrated on loglik_moments_kernel, whose compulsory reads are known)' % wl)
+try:
+    allj = json.load(open(out))
+except Exception:
+    allj = {}
+allj[wl] = res
+json.dump(allj, open(out, 'w'), indent=1)
