@@ -236,7 +236,7 @@ def main():
         if os.path.exists(tpath):
             # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/tools/collect_traffic.sh)
             tj = json.load(open(tpath))
-            traffic = tj.get(args.workload, {}).get(name)
+            traffic = tj.get('%s:%s' % (args.workload, mode), {}).get(name)     # measured per workload AND mode
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'kernel': name,
                 'kernel_ms': {k: v[0] * 1e3 for k, v in kern.items()},

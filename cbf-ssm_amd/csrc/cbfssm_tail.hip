@@ -183,11 +183,11 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
         p.g_z[idx] = gzt / p.ls[j];
     }
     __syncthreads();
-    if (tid < D) {
-        const int j = tid;
+    for (int j = wv; j < D; j += NT / 64) {              // one wave per column: lanes over the rows (fixed order)
         double s = 0.0;
-        for (int i = 0; i < M; ++i) s += p.g_z[i * D + j] * p.Zs[i * D + j];      // = Z~bar o z~ / ls
-        p.g_ls[j] = -(s + small[32 + j] / p.ls[j]) * sigmoid(p.ls_unc[j]);
+        for (int i = l; i < M; i += 64) s += p.g_z[i * D + j] * p.Zs[i * D + j];      // = Z~bar o z~ / ls
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (l == 0) p.g_ls[j] = -(s + small[32 + j] / p.ls[j]) * sigmoid(p.ls_unc[j]);
     }
     if (tid == 0) {
         const double var = p.var[0];

@@ -8,8 +8,16 @@ OUT=${1:-gpurun_out/final}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT
 cd $R
-bash profiles/tools/collect_traffic.sh C3 $OUT/traffic
-mkdir -p profiles/r01 && cp $OUT/traffic.traffic.json profiles/r01/traffic.json   # bench.py reads it below
+bash profiles/tools/collect_traffic.sh C3 $OUT/traffic train
+bash profiles/tools/collect_traffic.sh C3 $OUT/traffic_eval eval
+mkdir -p profiles/r01
+python3 - $OUT/traffic.traffic.json $OUT/traffic_eval.traffic.json profiles/r01/traffic.json <<'PY'
+import json, sys
+d = {}
+for f in sys.argv[1:3]:
+    d.update(json.load(open(f)))
+json.dump(d, open(sys.argv[3], 'w'), indent=1)     # bench.py reads it below
+PY
 python3 bench.py > $OUT/bench_train_C3.json 2> $OUT/bench_train_C3.err
 python3 bench.py --mode eval > $OUT/bench_eval_C3.json 2> $OUT/bench_eval_C3.err
 for w in C1 C2 C4; do python3 bench.py --workload $w --mode train --no-cpu-baseline > $OUT/bench_train_$w.json 2> $OUT/bench_train_$w.err; done

@@ -35,11 +35,15 @@ for k in sorted(fe):
     # the largest dispatches are the full launches (bench.py's per-kernel timing); the smaller ones are the pieces of the
     # chain-group split inside a whole step
     f, w = max(fe[k]), max(wr.get(k, [0.0]))
-    res[k] = int((f + w) * 1024)
-    print('%-24s fetch %.1f MB  write %.1f MB  (%d dispatches)' % (k, f * 1024 / 1e6, w * 1024 / 1e6, len(fe[k])))
-res['_note'] = ('bytes per full launch = (FETCH_SIZE + WRITE_SIZE) KiB x 1024 from separate rocprofv3 --pmc passes of '
-                '`bench.py --workload %s --steps 1 --warmup 1` (profiles/tools/collect_traffic.sh); no x2 correction: '
-                'the kernels load 8 B per lane (calibrated on loglik_moments_kernel, whose compulsory reads are known)' % wl)
+    res[k] = int((2.0 * f + w) * 1024)
+    print('%-24s fetch 2 x %.1f MB  write %.1f MB  (%d dispatches)' % (k, f * 1024 / 1e6, w * 1024 / 1e6, len(fe[k])))
+res['_note'] = ('bytes per full launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 from separate rocprofv3 --pmc passes of '
+                '`bench.py --workload %s --steps 1 --warmup 1` (profiles/tools/collect_traffic.sh).  FETCH_SIZE x 2 as '
+                'MI355X_MICROARCH.md (HBM) prescribes for coalesced streams: these kernels read 128..512 contiguous bytes '
+                'per wave-instruction (128-B requests tallied at 64 B).  Calibrated on the eval-mode backward pass, whose '
+                'compulsory reads are known (noise 41 MB + u, y 7 MB = 48 MB; FETCH_SIZE reports 22 MB), and on '
+                'loglik_moments_kernel for the opposite case (8-B reads at a 112-B stride: 147 MB compulsory, 156 MB '
+                'reported, no correction).' % wl.replace(':', ' --mode '))
 try:
     allj = json.load(open(out))
 except Exception:
