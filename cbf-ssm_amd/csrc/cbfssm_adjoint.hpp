@@ -231,6 +231,21 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     // while step s computes and lands in the other xq buffer; the epilogue adjoint of step s+1 (phase D) follows phase
     // G of step s in the same lanes, so a step has four workgroup barriers and no load latency on its critical path.
     auto t_of = [&](int step) -> int { return (MODE == MODE_FWD) ? (a.t_hi - step) : (t_begin + step); };
+    // auxiliary input rows of this thread: base pointer, time stride and 1/lengthscale, fixed for the whole pass
+    const double* auxp[AUXR];
+    int auxs[AUXR];
+    double auxl[AUXR];
+#pragma unroll
+    for (int k2 = 0; k2 < AUXR; ++k2) {
+        const int i = tid + k2 * NT, ja = i >> 4, n = i & 15;
+        auxp[k2] = nullptr; auxs[k2] = 0; auxl[k2] = 0.0;
+        if (i < 16 * naux) {
+            const int b = min(c0 + n, N - 1) / S;
+            if (ja < a.dim_u) { auxp[k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[k2] = a.dim_u; }
+            else { auxp[k2] = a.y + int64_t(b) * T * a.dim_y + (ja - a.dim_u); auxs[k2] = a.dim_y; }
+            auxl[k2] = a.pk.invl[Do + ja];
+        }
+    }
     auto load_inputs = [&](int t, double (&hv)[QPW], double (&av)[AUXR]) {
         bool rs = false;
         if (MODE == MODE_BWD) rs = (((t + 1 + run * R) % P) == 0);                            // cbfssm.py:124,127
@@ -248,10 +263,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             }
         }
 #pragma unroll
-        for (int k2 = 0; k2 < AUXR; ++k2) {
-            const int i = tid + k2 * NT;
-            av[k2] = (i < 16 * naux) ? aux_load(i, t) : 0.0;
-        }
+        for (int k2 = 0; k2 < AUXR; ++k2) av[k2] = auxp[k2] ? auxp[k2][int64_t(t) * auxs[k2]] * auxl[k2] : 0.0;
     };
     auto store_inputs = [&](double* xb, const double (&hv)[QPW], const double (&av)[AUXR]) {
 #pragma unroll
