@@ -167,16 +167,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
 #pragma unroll
     for (int k2 = 0; k2 < GPW; ++k2) glx[k2] = 0.0;
 
-    auto aux_load = [&](int i, int t) -> double {
-        const int ja = i >> 4, n = i & 15;
-        if (ja >= naux) return 0.0;
-        const int cc = min(c0 + n, N - 1);
-        const int b = cc / S;
-        double v;
-        if (ja < a.dim_u) v = a.u[(int64_t(b) * T + t) * a.dim_u + ja];
-        else v = a.y[(int64_t(b) * T + t) * a.dim_y + (ja - a.dim_u)];
-        return v * a.pk.invl[Do + ja];
-    };
 
     for (int i = tid; i < 2 * 4 * DK * PD; i += NT) xq0[i] = 0.0;
     double* xq = xq0;

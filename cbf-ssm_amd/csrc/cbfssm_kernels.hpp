@@ -553,15 +553,25 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     }
 
     // auxiliary (non-state) input rows: fwd u_t; bwd [u_t, y_t]           (cbfssm.py:137,197)
-    auto aux_load = [&](int cb, int i, int t) -> double {
-        const int ja = i >> 4, n = i & 15;
-        if (ja >= naux) return 0.0;
-        const int cx = min(c0 + cb * 16 + n, N - 1);
-        const int b = cx / S;
-        double v;
-        if (ja < a.dim_u) v = a.u[(int64_t(b) * T + t) * a.dim_u + ja];
-        else v = a.y[(int64_t(b) * T + t) * a.dim_y + (ja - a.dim_u)];
-        return v * a.pk.invl[Do + ja];
+    // auxiliary input rows of this thread: base pointer, time stride and 1/lengthscale are fixed for the whole pass
+    const double* auxp[NC][AUXR];
+    int auxs[NC][AUXR];
+    double auxl[NC][AUXR];
+#pragma unroll
+    for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+        for (int k2 = 0; k2 < AUXR; ++k2) {
+            const int i = tid + k2 * NT, ja = i >> 4, n = i & 15;
+            auxp[cb][k2] = nullptr; auxs[cb][k2] = 0; auxl[cb][k2] = 0.0;
+            if (i < 16 * naux) {
+                const int b = min(c0 + cb * 16 + n, N - 1) / S;
+                if (ja < a.dim_u) { auxp[cb][k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[cb][k2] = a.dim_u; }
+                else { auxp[cb][k2] = a.y + int64_t(b) * T * a.dim_y + (ja - a.dim_u); auxs[cb][k2] = a.dim_y; }
+                auxl[cb][k2] = a.pk.invl[Do + ja];
+            }
+        }
+    auto aux_load = [&](int cb, int k2, int t) -> double {
+        return auxp[cb][k2] ? auxp[cb][k2][int64_t(t) * auxs[cb][k2]] * auxl[cb][k2] : 0.0;
     };
 
     // ---- initial state and first input
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT;
-            if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = aux_load(cb, i, t_first);
+            if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = aux_load(cb, k2, t_first);
         }
 
     CBF_STAMP_DECL;
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 #pragma unroll
             for (int k2 = 0; k2 < AUXR; ++k2) {
                 const int i = tid + k2 * NT;
-                auxr[cb][k2] = (has_next && i < 16 * naux) ? aux_load(cb, i, tn) : 0.0;
+                auxr[cb][k2] = has_next ? aux_load(cb, k2, tn) : 0.0;
             }
 
         double* a2o = nullptr;                        // this step's A2 tiles, kept for the adjoint
@@ -811,15 +821,25 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
         }
     }
 
-    auto aux_load = [&](int cb, int i, int t) -> double {
-        const int ja = i >> 4, n = i & 15;
-        if (ja >= naux) return 0.0;
-        const int cx = min(c0 + cb * 16 + n, N - 1);
-        const int b = cx / S;
-        double v;
-        if (ja < a.dim_u) v = a.u[(int64_t(b) * T + t) * a.dim_u + ja];
-        else v = a.y[(int64_t(b) * T + t) * a.dim_y + (ja - a.dim_u)];
-        return v * a.pk.invl[Do + ja];
+    // auxiliary input rows of this thread: base pointer, time stride and 1/lengthscale are fixed for the whole pass
+    const double* auxp[2][AUXR];
+    int auxs[2][AUXR];
+    double auxl[2][AUXR];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int k2 = 0; k2 < AUXR; ++k2) {
+            const int i = tid + k2 * NT, ja = i >> 4, n = i & 15;
+            auxp[cb][k2] = nullptr; auxs[cb][k2] = 0; auxl[cb][k2] = 0.0;
+            if (i < 16 * naux) {
+                const int b = min(c0 + cb * 16 + n, N - 1) / S;
+                if (ja < a.dim_u) { auxp[cb][k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[cb][k2] = a.dim_u; }
+                else { auxp[cb][k2] = a.y + int64_t(b) * T * a.dim_y + (ja - a.dim_u); auxs[cb][k2] = a.dim_y; }
+                auxl[cb][k2] = a.pk.invl[Do + ja];
+            }
+        }
+    auto aux_load = [&](int cb, int k2, int t) -> double {
+        return auxp[cb][k2] ? auxp[cb][k2][int64_t(t) * auxs[cb][k2]] * auxl[cb][k2] : 0.0;
     };
 
     // ---- initial state and first input of both groups
@@ -849,7 +869,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT;
-            if (i < 16 * naux) xq[c * XS + 16 * Do + i] = aux_load(c, i, t_first);
+            if (i < 16 * naux) xq[c * XS + 16 * Do + i] = aux_load(c, k2, t_first);
         }
     }
     __syncthreads();
@@ -876,7 +896,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT;
-            auxn[k2] = (has_next && i < 16 * naux) ? aux_load(c, i, tn) : 0.0;
+            auxn[k2] = has_next ? aux_load(c, k2, tn) : 0.0;
         }
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
