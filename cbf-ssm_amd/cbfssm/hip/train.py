@@ -227,13 +227,9 @@ class HipElboGrad:
         else:
             gB_f, gB_b = self._adjoint_stash(prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red)
         # ---- data scalars and the log-likelihood's pull on var_y (cbfssm.py:245-251)
-        vy = c['var_y'][:self.dim_y]
-        ll_d = ws.ll_part.view(-1, self.dim_y).sum(0)
-        sq_d = (-2.0 * ll_d - B * T * self.S * (LOG2PI + torch.log(vy))) * vy
-        gvy_ll = -cL * 0.5 * (sq_d / (vy * vy) - B * T * self.S / vy)
         tail = red[sf + sb:]
-        tail[0:3] = ws.out[0:3]
-        tail[3:] = gvy_ll
+        _l.check(lib.cbfssm_data_tail_f64(pb, _ptr(c['var_y']), _ptr(ws.ll_part), _ptr(ws.out), cL, _ptr(tail), st),
+                 'cbfssm_data_tail_f64')
         if self.dist is not None:
             all_reduce_sum(red, self.dist)     # the one collective of a train step (RCCL over xGMI)
             if self.stash:
@@ -242,7 +238,10 @@ class HipElboGrad:
 
         loglik, kl_x, entropy = tail[0], tail[1], tail[2]
         kl_z_f, kl_z_b = self.pack_f.scal[_l.SCAL_KLZ], self.pack_b.scal[_l.SCAL_KLZ]
-        elbo = loglik * cL - kl_x * cL + entropy * cE - kl_z_f - kl_z_b                    # cbfssm.py:258-261
+        if self.dist is not None:
+            loss = -(loglik * cL - kl_x * cL + entropy * cE - kl_z_f - kl_z_b)             # cbfssm.py:258-261
+        else:
+            loss = ws.out[6].clone()                    # the same combination, done by cbfssm_elbo_combine_f64
         terms = {'loglik': loglik, 'kl_x': kl_x, 'entropy': entropy, 'kl_z_f': kl_z_f, 'kl_z_b': kl_z_b,
                  'info': ws.out[7]}
         if self.fused_tail:
@@ -252,7 +251,7 @@ class HipElboGrad:
                                            _ptr(gB_b), Mp, _ptr(pflat), _ptr(self.cflat), _ptr(self.tail_work),
                                            _ptr(self.gflat), st)
             _l.check(rc, 'cbfssm_train_tail_f64')
-            return -elbo, _flat_views(self.gflat, self.pl, self.dim_u), terms
+            return loss, _flat_views(self.gflat, self.pl, self.dim_u), terms
 
         # ---- once-per-step adjoints and the chain through the positivity transforms (tensor-library restatement)
         grads = {}
@@ -274,7 +273,7 @@ class HipElboGrad:
         grads['var_x_unc'] = gvx * torch.sigmoid(p['var_x_unc'])
         grads['var_y_unc'] = gvy * torch.sigmoid(p['var_y_unc'])
 
-        return -elbo, grads, terms
+        return loss, grads, terms
 
     # ---- chain-group split: chains never interact, so a pass can be issued in two pieces on two HIP streams.  When the
     # number of 16-chain groups is not a multiple of the CU count (C3: 320 groups on 256 CUs), the one-workgroup-per-

@@ -1,5 +1,6 @@
 // Per-NBLK instantiation of the adjoint kernels.
 #pragma once
+#include <cstdlib>
 #include "cbfssm_adjoint.hpp"
 #include "cbfssm_inst.hpp"
 
@@ -32,7 +33,7 @@ int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
     typedef RevGeom<NBLK, DK> G;
     typedef RevCfg<NBLK> C;
     const int blds_doubles = NBLK * a.KSr * 64;
-    if (G::LDS_BASE + blds_doubles <= G::LDS_LIMIT) {
+    if (G::LDS_BASE + blds_doubles <= G::LDS_LIMIT && !getenv("CBFSSM_NO_BLDS")) {
         const size_t lds = size_t(G::LDS_BASE + blds_doubles) * sizeof(double);
         auto k = rev_kernel<NBLK, C::RB, DK, true, C::STASH, MODE>;
         int rc = set_lds(k, lds);

@@ -290,6 +290,12 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
                           const double* gB_dense_f, const double* gB_dense_b, int64_t gB_ld, const double* pflat,
                           const double* cflat, double* work, double* gflat, void* stream);
 
+/* The rank-local data terms of the flat reduce buffer: tail[0..2] = loglik, kl_x, entropy (from the ELBO combination's
+ * out[0..2]); tail[3 + d] = d loss / d var_y[d] through the log-likelihood (cbfssm.py:245-251), d < dim_y, from the
+ * per-dimension totals of ll_part (cbfssm_loglik_moments_f64).  cL = loss_factors[0] / S. */
+int cbfssm_data_tail_f64(const cbfssm_problem* p, const double* var_y, const double* ll_part, const double* out8, double cL,
+                         double* tail, void* stream);
+
 /* tf.train.AdamOptimizer(learning_rate).minimize (cbfssm.py:273-275; TF 1.8 rule): t_dev (one double on the device)
  * is incremented, then lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), p -= lr_t m / (sqrt(v) + eps). */
 int cbfssm_adam_step_f64(int64_t n, double* pflat, const double* gflat, double* m, double* v, double* t_dev, double lr,
