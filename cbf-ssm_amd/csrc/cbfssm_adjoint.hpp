@@ -77,6 +77,10 @@ struct Slab {
     static constexpr int total = small + 192;            // [100,192): diagnostic stamps (CBF_REV_STAMPS builds only)
 };
 
+// 32-bit LDS address of a pointer into the dynamic shared array (for the hand-scheduled loop of phase F)
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ uint32_t lds_addr(const double* p) { return uint32_t(uintptr_t((lds_cdouble*)p)); }
+
 // BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the ceil(M/4)
 // k-steps that carry data); otherwise it streams from L2.  RB: 16-row blocks of inducing points per wave.
 template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE>
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     constexpr int PD = 17;                              // padded row length of the LDS tiles
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
     constexpr int NCB = STASH ? 1 : NBLK;
+    constexpr bool ALL_OK = (NBLK % RB == 0);           // every wave owns RB real row blocks (no predicate around MFMAs)
     typedef Slab<NBLK, JB, STASH> SL;
 
     extern __shared__ double lds[];
@@ -584,7 +589,62 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             d4 acc[RB][2];
 #pragma unroll
             for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
-            if constexpr (BLDS) {
+            if constexpr (BLDS && RB == 1) {
+                // Both operands come from LDS.  Left to the compiler the loop is read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs
+                // per iteration (half rate, measured): its wait insertion drains the counter on every back edge, also
+                // for a hand-unrolled two-set source.  So the loop over whole groups of four k-steps is ONE asm
+                // statement: two operand sets, the reads of the next pair in flight under the MFMAs of the current one,
+                // counted waits.  (Scalar loads also count on lgkmcnt but only make a wait longer.)  The trailing
+                // s_nops are what the compiler puts between an MFMA and a VALU read of its result.
+                const int nquad = KSr >> 2;
+                if (nquad > 0) {
+                    uint32_t adrA = lds_addr(bop[0]);               // + 512 bytes per k-step
+                    uint32_t adrB = lds_addr(A2t + g * PD + nl);    // + 4 * 17 * 8 = 544 bytes per k-step
+                    int cnt = nquad;
+                    double a0, a1, a2, a3, b0, b1, b2, b3;
+                    asm volatile(
+                        "ds_read_b64 %[a0], %[pa]\n\t"
+                        "ds_read_b64 %[b0], %[pb]\n\t"
+                        "ds_read_b64 %[a1], %[pa] offset:512\n\t"
+                        "ds_read_b64 %[b1], %[pb] offset:544\n"
+                        "1:\n\t"
+                        "ds_read_b64 %[a2], %[pa] offset:1024\n\t"
+                        "ds_read_b64 %[b2], %[pb] offset:1088\n\t"
+                        "ds_read_b64 %[a3], %[pa] offset:1536\n\t"
+                        "ds_read_b64 %[b3], %[pb] offset:1632\n\t"
+                        "s_waitcnt lgkmcnt(4)\n\t"
+                        "v_mfma_f64_16x16x4_f64 %[c0], %[a0], %[b0], %[c0]\n\t"
+                        "v_mfma_f64_16x16x4_f64 %[c1], %[a1], %[b1], %[c1]\n\t"
+                        "s_sub_u32 %[n], %[n], 1\n\t"
+                        "v_add_u32 %[pa], 0x800, %[pa]\n\t"
+                        "v_add_u32 %[pb], 0x880, %[pb]\n\t"
+                        "s_cmp_eq_u32 %[n], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "ds_read_b64 %[a0], %[pa]\n\t"
+                        "ds_read_b64 %[b0], %[pb]\n\t"
+                        "ds_read_b64 %[a1], %[pa] offset:512\n\t"
+                        "ds_read_b64 %[b1], %[pb] offset:544\n\t"
+                        "s_waitcnt lgkmcnt(4)\n\t"
+                        "v_mfma_f64_16x16x4_f64 %[c0], %[a2], %[b2], %[c0]\n\t"
+                        "v_mfma_f64_16x16x4_f64 %[c1], %[a3], %[b3], %[c1]\n\t"
+                        "s_branch 1b\n"
+                        "2:\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_mfma_f64_16x16x4_f64 %[c0], %[a2], %[b2], %[c0]\n\t"
+                        "v_mfma_f64_16x16x4_f64 %[c1], %[a3], %[b3], %[c1]\n\t"
+                        "s_nop 15\n\t"
+                        "s_nop 2"
+                        : [c0] "+v"(acc[0][0]), [c1] "+v"(acc[0][1]), [pa] "+v"(adrA), [pb] "+v"(adrB), [n] "+s"(cnt),
+                          [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
+                          [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3)
+                        :
+                        : "scc", "memory");
+                }
+                for (int s = 4 * nquad; s < KSr; ++s) {             // the 0..3 k-steps left
+                    const double bt = A2t[(4 * s + g) * PD + nl];
+                    acc[0][s & 1] = CBF_MFMA(bop[0][s * 64], bt, acc[0][s & 1]);
+                }
+            } else if constexpr (BLDS) {
                 int s = 0;
 #pragma unroll 2
                 for (; s + 1 < KSr; s += 2) {
