@@ -77,9 +77,6 @@ struct Slab {
     static constexpr int total = small + 192;            // [100,192): diagnostic stamps (CBF_REV_STAMPS builds only)
 };
 
-// 32-bit LDS address of a pointer into the dynamic shared array (for the hand-scheduled loop of phase F)
-typedef __attribute__((address_space(3))) const double lds_cdouble;
-__device__ __forceinline__ uint32_t lds_addr(const double* p) { return uint32_t(uintptr_t((lds_cdouble*)p)); }
 
 // BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the ceil(M/4)
 // k-steps that carry data); otherwise it streams from L2.  RB: 16-row blocks of inducing points per wave.
@@ -474,9 +471,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                     for (int i = 0; i < RB; ++i)
                         if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
                 }
+            } else if constexpr (RB == 2 && NBLK >= 16) {
+                // (measured: -6 % on the C5 step at NBLK = 20; at NBLK = 13 the 48 fixed registers cost more in spills than
+                // the loop gains)
+                // K^-1 streams from L2 through the hand-scheduled loop (cbfssm_kernels.hpp); the image is zero-padded to
+                // KS = 4 NBLK k-steps, the tile rows beyond M are finite, a non-existent second row block is dropped
+                stream_kinv_rb2<4 * PD * 8>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bop[0], bop[1],
+                                            lds_addr(Kt + g * PD + nl), (KSr + 3) >> 2);
             } else {
-                // K^-1 streams from L2: issue the operand loads of four k-steps together, ahead of their MFMAs (the
-                // image is zero-padded to KS = 4 NBLK k-steps, the tile rows beyond M are finite)
+                // K^-1 streams from L2: issue the operand loads of four k-steps together, ahead of their MFMAs
 #pragma unroll 1
                 for (int s0 = 0; s0 < KSr; s0 += 4) {
                     double b[4], aop[RB][4];
@@ -663,9 +666,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                     for (int i = 0; i < RB; ++i)
                         if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
                 }
+            } else if constexpr (RB == 2 && NBLK >= 16) {
+                // (measured: -6 % on the C5 step at NBLK = 20; at NBLK = 13 the 48 fixed registers cost more in spills than
+                // the loop gains)
+                // K^-1 streams from L2 through the hand-scheduled loop (cbfssm_kernels.hpp); the image is zero-padded to
+                // KS = 4 NBLK k-steps, the tile rows beyond M are finite, a non-existent second row block is dropped
+                stream_kinv_rb2<4 * PD * 8>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bop[0], bop[1],
+                                            lds_addr(A2t + g * PD + nl), (KSr + 3) >> 2);
             } else {
-                // K^-1 streams from L2: issue the operand loads of four k-steps together, ahead of their MFMAs (the
-                // image is zero-padded to KS = 4 NBLK k-steps, the tile rows beyond M are finite)
+                // K^-1 streams from L2: issue the operand loads of four k-steps together, ahead of their MFMAs
 #pragma unroll 1
                 for (int s0 = 0; s0 < KSr; s0 += 4) {
                     double b[4], aop[RB][4];

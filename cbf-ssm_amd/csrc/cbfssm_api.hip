@@ -596,14 +596,16 @@ static int pass_nc(const cbfssm_problem* p, int mode)
     const int64_t n = int64_t(p->B) * p->S;
     const char* e = getenv(mode == MODE_FWD ? "CBFSSM_NC_FWD" : "CBFSSM_NC_BWD");
     // tile heights 13..16 (two row blocks per wave): two column blocks share every streamed K^-1 operand load; their
-    // tiles fit the LDS up to M = 256.  Measured at C4: backward pass 8.25 -> 6.96 ms, forward pass 6.60 -> 5.53 ms.
+    // tiles fit the LDS up to M = 256.  Measured at C4 against the compiler-scheduled one-block kernel: backward pass
+    // 8.25 -> 6.96 ms, forward pass 6.60 -> 5.53 ms (CBFSSM_NC_FWD / CBFSSM_NC_BWD = 3).
     const bool shared_ok = p->M > 192 && p->M <= 256 && !p->half;
     if (e && !p->half) {
         const int v = atoi(e);
         if (p->M > 112) return (v == 3 && shared_ok) ? 3 : 1;
         return (v == 2 || v == 3) ? v : 1;
     }
-    if (p->M > 112) return (shared_ok && n >= 32 * 128) ? 3 : 1;   // (the skewed kernel's two tiles do not fit there)
+    if (p->M > 112) return 1;   // (the skewed kernel's two tiles do not fit; the shared-operand variant 3 equals the
+                                //  hand-scheduled one-block kernel at C4: 6.96 vs 6.95 ms, so it stays opt-in)
     // measured at C3: the skewed two-group kernel is 3 % faster on the many-workgroup backward runs and 2 % slower
     // on the forward pass (320 -> 160 workgroups)
     if (mode == MODE_BWD) return n >= 32 * 128 ? 2 : 1;

@@ -66,6 +66,143 @@ enum { MODE_FWD = 0, MODE_BWD = 1 };
 
 
 
+// 32-bit LDS address of a pointer into the dynamic shared array (for the hand-scheduled loops)
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ uint32_t lds_addr(const double* p) { return uint32_t(uintptr_t((lds_cdouble*)p)); }
+
+// acc[i][h] += sum over `ngrp` groups of four k-steps of A_i[s] x B[s]   (i = the wave's two row blocks, h = s & 1)
+//   A_i: lane-linear K^-1 operand image in global memory / L2, 512 bytes per k-step, this lane's first element at pa_i
+//   B:   operand tile in LDS, BSTRIDE bytes per k-step, this lane's first element at LDS address ldsb
+// Hand-scheduled: written as a source loop, hipcc's wait insertion drains vmcnt/lgkmcnt on the loop back edge, so every
+// group of four k-steps waits out an L2 latency before its MFMAs.  Here two operand sets (fixed registers v120..v167,
+// declared as clobbers: inside the 168-register budget of the 10-wave workgroups) alternate: the twelve loads of group g+1 are in flight under the eight MFMAs of group g, the
+// waits are counted.  The images are zero-padded to whole groups; the trailing s_nops are what the compiler puts
+// between an MFMA and a VALU read of its result.
+template <int BSTRIDE>
+__device__ __forceinline__ void stream_kinv_rb2(d4& c00, d4& c01, d4& c10, d4& c11, const double* pa0, const double* pa1,
+                                                uint32_t ldsb, int ngrp)
+{
+    static_assert(7 * BSTRIDE < 65536, "ds_read offset field");
+    if (ngrp <= 0) return;
+    const unsigned long long step = 4096;           // bytes of K^-1 image per two groups
+    asm volatile(
+        "global_load_dwordx2 v[120:121], %[pa0], off offset:0\n\t"
+        "global_load_dwordx2 v[128:129], %[pa1], off offset:0\n\t"
+        "ds_read_b64 v[136:137], %[pb] offset:%[bs0]\n\t"
+        "global_load_dwordx2 v[122:123], %[pa0], off offset:512\n\t"
+        "global_load_dwordx2 v[130:131], %[pa1], off offset:512\n\t"
+        "ds_read_b64 v[138:139], %[pb] offset:%[bs1]\n\t"
+        "global_load_dwordx2 v[124:125], %[pa0], off offset:1024\n\t"
+        "global_load_dwordx2 v[132:133], %[pa1], off offset:1024\n\t"
+        "ds_read_b64 v[140:141], %[pb] offset:%[bs2]\n\t"
+        "global_load_dwordx2 v[126:127], %[pa0], off offset:1536\n\t"
+        "global_load_dwordx2 v[134:135], %[pa1], off offset:1536\n\t"
+        "ds_read_b64 v[142:143], %[pb] offset:%[bs3]\n\t"
+        "1:\n"
+        "s_cmp_lt_u32 %[n], 3\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "global_load_dwordx2 v[144:145], %[pa0], off offset:2048\n\t"
+        "global_load_dwordx2 v[152:153], %[pa1], off offset:2048\n\t"
+        "ds_read_b64 v[160:161], %[pb] offset:%[bs4]\n\t"
+        "global_load_dwordx2 v[146:147], %[pa0], off offset:2560\n\t"
+        "global_load_dwordx2 v[154:155], %[pa1], off offset:2560\n\t"
+        "ds_read_b64 v[162:163], %[pb] offset:%[bs5]\n\t"
+        "global_load_dwordx2 v[148:149], %[pa0], off offset:3072\n\t"
+        "global_load_dwordx2 v[156:157], %[pa1], off offset:3072\n\t"
+        "ds_read_b64 v[164:165], %[pb] offset:%[bs6]\n\t"
+        "global_load_dwordx2 v[150:151], %[pa0], off offset:3584\n\t"
+        "global_load_dwordx2 v[158:159], %[pa1], off offset:3584\n\t"
+        "ds_read_b64 v[166:167], %[pb] offset:%[bs7]\n\t"
+        "s_waitcnt vmcnt(8) lgkmcnt(4)\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[120:121], v[136:137], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[128:129], v[136:137], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[122:123], v[138:139], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[130:131], v[138:139], %[c11]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[124:125], v[140:141], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[132:133], v[140:141], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[126:127], v[142:143], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[134:135], v[142:143], %[c11]\n\t"
+        "v_lshl_add_u64 %[pa0], %[pa0], 0, %[step]\n\t"
+        "v_lshl_add_u64 %[pa1], %[pa1], 0, %[step]\n\t"
+        "v_add_u32 %[pb], %[bs8], %[pb]\n\t"
+        "s_sub_u32 %[n], %[n], 2\n\t"
+        "global_load_dwordx2 v[120:121], %[pa0], off offset:0\n\t"
+        "global_load_dwordx2 v[128:129], %[pa1], off offset:0\n\t"
+        "ds_read_b64 v[136:137], %[pb] offset:%[bs0]\n\t"
+        "global_load_dwordx2 v[122:123], %[pa0], off offset:512\n\t"
+        "global_load_dwordx2 v[130:131], %[pa1], off offset:512\n\t"
+        "ds_read_b64 v[138:139], %[pb] offset:%[bs1]\n\t"
+        "global_load_dwordx2 v[124:125], %[pa0], off offset:1024\n\t"
+        "global_load_dwordx2 v[132:133], %[pa1], off offset:1024\n\t"
+        "ds_read_b64 v[140:141], %[pb] offset:%[bs2]\n\t"
+        "global_load_dwordx2 v[126:127], %[pa0], off offset:1536\n\t"
+        "global_load_dwordx2 v[134:135], %[pa1], off offset:1536\n\t"
+        "ds_read_b64 v[142:143], %[pb] offset:%[bs3]\n\t"
+        "s_waitcnt vmcnt(8) lgkmcnt(4)\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[144:145], v[160:161], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[152:153], v[160:161], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[146:147], v[162:163], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[154:155], v[162:163], %[c11]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[148:149], v[164:165], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[156:157], v[164:165], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[150:151], v[166:167], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[158:159], v[166:167], %[c11]\n\t"
+        "s_branch 1b\n\t"
+        "2:\n"
+        "s_cmp_eq_u32 %[n], 2\n\t"
+        "s_cbranch_scc0 3f\n\t"
+        "global_load_dwordx2 v[144:145], %[pa0], off offset:2048\n\t"
+        "global_load_dwordx2 v[152:153], %[pa1], off offset:2048\n\t"
+        "ds_read_b64 v[160:161], %[pb] offset:%[bs4]\n\t"
+        "global_load_dwordx2 v[146:147], %[pa0], off offset:2560\n\t"
+        "global_load_dwordx2 v[154:155], %[pa1], off offset:2560\n\t"
+        "ds_read_b64 v[162:163], %[pb] offset:%[bs5]\n\t"
+        "global_load_dwordx2 v[148:149], %[pa0], off offset:3072\n\t"
+        "global_load_dwordx2 v[156:157], %[pa1], off offset:3072\n\t"
+        "ds_read_b64 v[164:165], %[pb] offset:%[bs6]\n\t"
+        "global_load_dwordx2 v[150:151], %[pa0], off offset:3584\n\t"
+        "global_load_dwordx2 v[158:159], %[pa1], off offset:3584\n\t"
+        "ds_read_b64 v[166:167], %[pb] offset:%[bs7]\n\t"
+        "s_waitcnt vmcnt(8) lgkmcnt(4)\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[120:121], v[136:137], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[128:129], v[136:137], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[122:123], v[138:139], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[130:131], v[138:139], %[c11]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[124:125], v[140:141], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[132:133], v[140:141], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[126:127], v[142:143], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[134:135], v[142:143], %[c11]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[144:145], v[160:161], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[152:153], v[160:161], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[146:147], v[162:163], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[154:155], v[162:163], %[c11]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[148:149], v[164:165], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[156:157], v[164:165], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[150:151], v[166:167], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[158:159], v[166:167], %[c11]\n\t"
+        "s_branch 4f\n\t"
+        "3:\n"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[120:121], v[136:137], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[128:129], v[136:137], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[122:123], v[138:139], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[130:131], v[138:139], %[c11]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c00], v[124:125], v[140:141], %[c00]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c10], v[132:133], v[140:141], %[c10]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c01], v[126:127], v[142:143], %[c01]\n\t"
+        "v_mfma_f64_16x16x4_f64 %[c11], v[134:135], v[142:143], %[c11]\n\t"
+        "4:\n"
+        "s_nop 15\n\t"
+        "s_nop 2\n\t"
+        : [c00] "+v"(c00), [c01] "+v"(c01), [c10] "+v"(c10), [c11] "+v"(c11), [pa0] "+v"(pa0), [pa1] "+v"(pa1),
+          [pb] "+v"(ldsb), [n] "+s"(ngrp)
+        : [step] "s"(step), [bs0] "n"(0 * BSTRIDE), [bs1] "n"(1 * BSTRIDE), [bs2] "n"(2 * BSTRIDE), [bs3] "n"(3 * BSTRIDE),
+          [bs4] "n"(4 * BSTRIDE), [bs5] "n"(5 * BSTRIDE), [bs6] "n"(6 * BSTRIDE), [bs7] "n"(7 * BSTRIDE),
+          [bs8] "n"(8 * BSTRIDE)
+        : "scc", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
+}
+
 struct PackPtrs {
     const double* Bp;
     const double* Zp;
@@ -344,6 +481,11 @@ struct Tile {
                 for (int i = 0; i < RB; ++i)
                     if (w * RB + i < NBLK) acc[i][s & 1] = CBF_MFMA(Breg[i][s], b, acc[i][s & 1]);
             }
+        } else if constexpr (RB == 2) {
+            // (a wave whose second row block does not exist runs it on a copy of the last block; the result is dropped)
+            const int rb0 = min(w * 2, NBLK - 1), rb1 = min(w * 2 + 1, NBLK - 1);
+            stream_kinv_rb2<512>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], Bp + (rb0 * KS) * 64 + l,
+                                 Bp + (rb1 * KS) * 64 + l, lds_addr(Kt + l), (KSr + 3) >> 2);
         } else {
 #pragma unroll 1
             for (int s0 = 0; s0 < KSr; s0 += 4) {
