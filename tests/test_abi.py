@@ -36,3 +36,21 @@ def test_layout_is_host_only_and_consistent():
         except lib.CbfssmHipError:
             pass
     assert lib.load().cbfssm_version() >= 1
+
+
+def test_param_layout_is_host_only_and_ordered():
+    """cbfssm_param_layout_init: the twelve tensors of CBFSSM._setup_vars (reference cbfssm.py:30-58) in PARAM order."""
+    pl = lib.param_layout(100, 14, 7, 7)
+    M, D, dx, dob = 100, 21, 14, 7
+    sizes = [M * D, M * dx, M * dx, 1, D, M * D, M * dob, M * dob, 1, D, dx, dx]
+    off = 0
+    for k, n in enumerate(sizes):
+        assert pl.off[k] == off, k
+        off += n
+    assert pl.total == off and (pl.M, pl.D, pl.dim_x, pl.dim_y) == (M, D, dx, 7)
+    for bad in ((0, 4, 1, 1), (10, 4, 1, 5), (10, 0, 1, 1)):
+        try:
+            lib.param_layout(*bad)
+            assert False, bad
+        except lib.CbfssmHipError:
+            pass

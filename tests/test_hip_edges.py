@@ -85,3 +85,60 @@ def test_non_pd_kmm_raises_through_the_model_surface(tmp_path):
         model.load_ds(sess, ds.train_in_batch, ds.train_out_batch)
         with pytest.raises(InvalidArgumentError):
             sess.run(model.loss, {model.condition: True})
+
+
+def test_train_tail_entry_points_through_the_abi():
+    """cbfssm_constrain_f64, cbfssm_data_tail_f64 and cbfssm_adam_step_f64 called directly (ctypes) against numpy."""
+    import ctypes as C
+    from cbfssm.hip import lib, ops
+    l = lib.load()
+    rng = np.random.default_rng(3)
+    M, dx, du, dy = 9, 5, 2, 2
+    pl = lib.param_layout(M, dx, du, dy)
+    n = int(pl.total)
+    p = rng.standard_normal(n) * 3.0
+    p[7] = 40.0          # softplus of a large argument
+    p[8] = -40.0
+    dp = torch.tensor(p, device=DEV)
+    dc = torch.zeros_like(dp)
+    st = ops._stream()
+    lib.check(l.cbfssm_constrain_f64(C.byref(pl), ops._ptr(dp), ops._ptr(dc), st), 'constrain')
+    unc = np.zeros(n, dtype=bool)
+    for k in (2, 3, 4, 7, 8, 9, 10, 11):                      # the *_unc tensors
+        hi = pl.off[k + 1] if k < 11 else n
+        unc[pl.off[k]:hi] = True
+    ref = np.where(unc, np.logaddexp(0.0, p) + 1e-10, p)      # tf_transform.py:19-21
+    np.testing.assert_allclose(dc.cpu().numpy(), ref, rtol=1e-14, atol=1e-300)
+
+    # Adam, TF 1.8 rule, three steps with fresh gradients
+    m = torch.zeros_like(dp); v = torch.zeros_like(dp); t = torch.zeros(1, dtype=torch.float64, device=DEV)
+    pn, mn, vn = p.copy(), np.zeros(n), np.zeros(n)
+    lr, b1, b2, eps = 0.05, 0.9, 0.999, 1e-8
+    for k in range(1, 4):
+        g = rng.standard_normal(n)
+        dg = torch.tensor(g, device=DEV)
+        lib.check(l.cbfssm_adam_step_f64(n, ops._ptr(dp), ops._ptr(dg), ops._ptr(m), ops._ptr(v), ops._ptr(t), lr, b1, b2,
+                                         eps, st), 'adam')
+        mn = b1 * mn + (1 - b1) * g
+        vn = b2 * vn + (1 - b2) * g * g
+        pn = pn - lr * np.sqrt(1 - b2 ** k) / (1 - b1 ** k) * mn / (np.sqrt(vn) + eps)
+    assert float(t[0]) == 3.0
+    np.testing.assert_allclose(dp.cpu().numpy(), pn, rtol=1e-13, atol=1e-15)
+
+    # data tail: per-dimension totals of the block partials -> d loss / d var_y   (cbfssm.py:245-251)
+    B, T, S = 3, 7, 4
+    prob = lib.make_problem(B, S, T, dx, du, dy, M, 2, 1.0, True)
+    nll = int(l.cbfssm_loglik_partials(C.byref(prob)))
+    llp = rng.standard_normal(nll)
+    vy = rng.uniform(0.1, 2.0, dx)
+    out8 = rng.standard_normal(8)
+    tail = torch.zeros(3 + dy, dtype=torch.float64, device=DEV)
+    cL = 0.37
+    d_vy, d_ll, d_o8 = torch.tensor(vy, device=DEV), torch.tensor(llp, device=DEV), torch.tensor(out8, device=DEV)
+    lib.check(l.cbfssm_data_tail_f64(C.byref(prob), ops._ptr(d_vy), ops._ptr(d_ll), ops._ptr(d_o8), cL, ops._ptr(tail), st),
+              'data tail')
+    ll_d = llp.reshape(-1, dy).sum(0)
+    bts = B * T * S
+    sq = (-2.0 * ll_d - bts * (np.log(2 * np.pi) + np.log(vy[:dy]))) * vy[:dy]
+    ref_t = np.concatenate([out8[:3], -cL * 0.5 * (sq / vy[:dy] ** 2 - bts / vy[:dy])])
+    np.testing.assert_allclose(tail.cpu().numpy(), ref_t, rtol=1e-12, atol=1e-14)
