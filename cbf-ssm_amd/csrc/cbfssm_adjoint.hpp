@@ -433,10 +433,19 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             kreg[i] = d4{0, 0, 0, 0};
             if (ok[i]) {
                 d4 e;
+                if constexpr (STASH) {
+                    // (stash mode runs two row blocks per wave at the VGPR cap: the Z~ operand and the row constants
+                    //  are re-read from their L1-resident images here instead of living in 40 registers for the pass)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[r] = a.pk.cz[16 * rbs[i] + 4 * r + g] - 0.5 * xx;
+#pragma unroll
+                    for (int s = 0; s < DK; ++s) e = CBF_MFMA(a.pk.Zp[(rbs[i] * DK + s) * 64 + l], bx[s], e);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) e[r] = tile.czr[i][r] - 0.5 * xx;
 #pragma unroll
                 for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[i][s], bx[s], e);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     kreg[i][r] = exp(e[r]);
@@ -691,11 +700,27 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                             if (ok[i]) acc[i][j & 1] = CBF_MFMA(aop[i][j], b[j], acc[i][j & 1]);
                 }
             }
+            if constexpr (STASH) {
+                // the kernel tile and (when the forward evaluation kept it) A2 are re-read here instead of staying in
+                // 32 registers across phases E and F: K from this wave's own rows of the LDS tile, A2 from L2
+                const bool a2_saved = (a.a2s != nullptr);
+                const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                const double* ap = a2_saved ? a.a2s + (slot * ((N + 15) >> 4) + (c0 >> 4)) * (NBLK * 256) + l : nullptr;
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double kv = Kt[(16 * rbs[i] + 4 * r + g) * PD + nl];
+                        const double av = a2_saved ? ap[rbs[i] * 256 + r * 64] : a2[i][r];
+                        ebar[i][r] = (acc[i][0][r] + acc[i][1][r] - av * fvsum) * kv;
+                    }
+            } else {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     ebar[i][r] = (acc[i][0][r] + acc[i][1][r] - a2[i][r] * fvsum) * kreg[i][r];
+            }
         }
         CBF_STAMP_MARK(6);
         {
