@@ -86,8 +86,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # rehearsal on a one-GPU box: CBFSSM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 with the gloo backend (the
+        # collective then goes through the host, cbfssm/hip/dist_utils.py); the real run is one rank per GPU over RCCL
+        if os.environ.get('CBFSSM_BENCH_ONE_DEVICE'):
+            local_rank = 0
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -149,7 +155,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     loss = float(out[6]) if mode == 'eval' else float(out)
@@ -177,7 +183,11 @@ def main():
 
         if mode == 'train' and not stepper.engine.stash:
             eng2 = stepper.engine
-            eng2.loss_and_grads(stepper.params, u, y, noise)          # fills the saved trajectories
+            group, eng2.dist = eng2.dist, None     # rank-local from here on: the other ranks do not take part
+            try:
+                eng2.loss_and_grads(stepper.params, u, y, noise)      # fills the saved trajectories
+            finally:
+                eng2.dist = group
             ws = eng2.last_ws
             cst = eng2._constrained({k: v for k, v in stepper.params.items()})
             var_x, var_y = cst['var_x'], cst['var_y']
@@ -266,6 +276,7 @@ def main():
             rec['cpu_baseline'] = None
         print(json.dumps(rec))
     if world > 1:
+        dist.barrier()           # rank 0 times its kernels and the CPU baseline alone; leave together
         dist.destroy_process_group()
 
 
