@@ -1,15 +1,18 @@
 // Reverse-mode (adjoint) time-loop kernels of the CBF-SSM ELBO: what tf.train.AdamOptimizer.minimize differentiates
 // through the two tf.while_loops (cbfssm/model/cbfssm.py:107-111,176-179,273-275), re-derived by hand.
 //
-// One workgroup owns 16 chains and walks the recurrence backwards.  Nothing of size (M,N) is ever stored: every
-// step recomputes K = k(Z, x_t) and A2 = K^-1 K from the saved trajectory (x_t or h_t), then
+// One workgroup owns 16 chains and walks the recurrence backwards from the saved trajectory (x_t or h_t).  Of the
+// forward evaluation it reads the per-step (fmean, fvar) and, when they were kept, the A2 = K^-1 K tiles; the kernel
+// tile K = k(Z, x_t) is recomputed (and A2 too when no tiles were kept: phase C).  Per step, between four workgroup
+// barriers:
 //
-//   D   per-(chain, dim) adjoint of the step epilogue  ->  Fm = d loss/d fmean, Fv = d loss/d fvar      (16 x 16 each)
+//   B   K tile of this wave's rows (MFMA + exp) -> LDS;           (the next step's inputs are loaded meanwhile)
 //   E   A2bar = mu Fm + 2 A2 o (s2 Fv) - K o colsum(Fv)                                                  MFMA
 //       mubar += A2 Fm^T,  s2bar += (A2 o A2) Fv^T,  Kinvbar += A2bar K^T      (k-dim = the 16 chains)    MFMA
 //   F   Kbar = Kinv A2bar - A2 o colsum(Fv);  Ebar = Kbar o K                                            MFMA
 //       xbar~ = Z~^T Ebar - x~ o colsum(Ebar),  Zbar~ += Ebar x~^T                                       MFMA
-//   G   carry d loss/d x_t (or d loss/d h_t) to the next reverse step
+//   G   carry d loss/d x_t (or d loss/d h_t) to the next reverse step, then in the same lanes
+//   D   per-(chain, dim) adjoint of the NEXT step's epilogue -> Fm = d loss/d fmean, Fv = d loss/d fvar  (16 x 16 each)
 //
 // Parameter adjoints accumulate in VGPRs over the whole pass and leave the kernel once, as one partial slab per
 // workgroup (summed in a fixed order by reduce_partials_kernel: bitwise reproducible, no atomics).
@@ -272,108 +275,108 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     // phase D of step t: adjoint of the step epilogue from the carried state adjoint -> Fm, Fv tiles, gdir
     // inputs of phase D of step t: {eps, y~ (fwd) or the y2 adjoint (bwd), fmean, fvar}
     auto epilogue_load = [&](int t, double& eps_t, double (&ytil)[QPW], double (&fmv_m)[QPW], double (&fmv_v)[QPW]) {
-            double (&gy2in)[QPW] = ytil;
-            if (MODE == MODE_FWD) {
-                eps_t = a.eps[int64_t(t) * N + c];
-#pragma unroll
-                for (int qi = 0; qi < QPW; ++qi) {
-                    const int d = 4 * (w + qi * W) + g;
-                    ytil[qi] = 0.0;
-                    if (act[qi]) {
-                        if (d < a.dim_y) ytil[qi] = a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d];
-                        else if (!a.half) ytil[qi] = a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)];
-                    }
-                }
-            } else {
-                eps_t = a.eps[(int64_t(run) * T + t) * N + c];
-#pragma unroll
-                for (int qi = 0; qi < QPW; ++qi) {
-                    const int d = 4 * (w + qi * W) + g;
-                    gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
-                }
-            }
+        double (&gy2in)[QPW] = ytil;
+        if (MODE == MODE_FWD) {
+            eps_t = a.eps[int64_t(t) * N + c];
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) {
                 const int d = 4 * (w + qi * W) + g;
-                fmv_m[qi] = 0.0; fmv_v[qi] = 1.0;
+                ytil[qi] = 0.0;
                 if (act[qi]) {
-                    const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
-                    const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
-                    fmv_m[qi] = o[0]; fmv_v[qi] = o[1];
+                    if (d < a.dim_y) ytil[qi] = a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d];
+                    else if (!a.half) ytil[qi] = a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)];
                 }
             }
+        } else {
+            eps_t = a.eps[(int64_t(run) * T + t) * N + c];
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int d = 4 * (w + qi * W) + g;
+                gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int d = 4 * (w + qi * W) + g;
+            fmv_m[qi] = 0.0; fmv_v[qi] = 1.0;
+            if (act[qi]) {
+                const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
+                fmv_m[qi] = o[0]; fmv_v[qi] = o[1];
+            }
+        }
     };
     auto epilogue_adjoint = [&](int t, const double eps_t, const double (&ytil)[QPW], const double (&fmv_m)[QPW],
                                 const double (&fmv_v)[QPW]) {
-            const double (&gy2in)[QPW] = ytil;
+        const double (&gy2in)[QPW] = ytil;
 #pragma unroll
-            for (int qi = 0; qi < QPW; ++qi) {
-                const int q = w + qi * W;
-                if (q < 4) {
-                    const int d = 4 * q + g;
-                    double gfm = 0.0, gfv = 0.0;
-                    if (act[qi] && cvalid) {
-                        const double fmean = fmv_m[qi];        // saved by the forward evaluation (no recompute of P1/P2)
-                        const double fvar = fmv_v[qi];
-                        const double gout = gcar[qi];
-                        if (MODE == MODE_FWD) {
-                            const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // cbfssm.py:227
-                            if (do_cond) {
-                                const double kf1 = a.k_factor - 1.0;
-                                const double vyt = vy[qi] + kf1 * fvar;
-                                const double s = vyt + fvar;
-                                const double rs = 1.0 / s;
-                                const double k = fvar * rs;
-                                const double ydiff = ytil[qi] - fmean;
-                                const double mu = fmean + k * ydiff;
-                                const double omk = 1.0 - k;
-                                const double sig = omk * omk * fvar + k * k * vyt;
-                                const double rf = 1.0 / fvar, rsig = 1.0 / sig;
-                                const double dm = mu - fmean;
-                                // x' = mu + eps sqrt(sig);  kl = .5[log fvar - log sig + (sig + dm^2)/fvar - 1]
-                                const double gmu = gout + a.cL * dm * rf;
-                                const double gsg = gout * eps_t * 0.5 * sqrt(rsig) + a.cL * 0.5 * (rf - rsig);
-                                gfm = -a.cL * dm * rf;
-                                gfv = a.cL * 0.5 * (rf - (sig + dm * dm) * rf * rf);
-                                // mu = fmean + k (ytil - fmean)
-                                gfm += gmu * omk;
-                                double gk = gmu * ydiff;
-                                const double gyt = gmu * k;
-                                // sig = (1-k)^2 fvar + k^2 vyt
-                                gk += gsg * (-2.0 * omk * fvar + 2.0 * k * vyt);
-                                gfv += gsg * omk * omk;
-                                double gvyt = gsg * k * k;
-                                // k = fvar / s ; s = vyt + fvar ; vyt = vy + (kf-1) fvar
-                                gfv += gk * rs;
-                                const double gs = -gk * k * rs;
-                                gvyt += gs;
-                                gfv += gs;
-                                gvy[qi] += gvyt;
-                                gfv += kf1 * gvyt;
-                                if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = gyt;
-                            } else {
-                                // x' = fmean + eps sqrt(fvar), no KL term                           (cbfssm.py:224,234)
-                                gfm = gout;
-                                gfv = gout * eps_t * 0.5 / sqrt(fvar);
-                                if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
-                            }
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int q = w + qi * W;
+            if (q < 4) {
+                const int d = 4 * q + g;
+                double gfm = 0.0, gfv = 0.0;
+                if (act[qi] && cvalid) {
+                    const double fmean = fmv_m[qi];        // saved by the forward evaluation (no recompute of P1/P2)
+                    const double fvar = fmv_v[qi];
+                    const double gout = gcar[qi];
+                    if (MODE == MODE_FWD) {
+                        const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // cbfssm.py:227
+                        if (do_cond) {
+                            const double kf1 = a.k_factor - 1.0;
+                            const double vyt = vy[qi] + kf1 * fvar;
+                            const double s = vyt + fvar;
+                            const double rs = 1.0 / s;
+                            const double k = fvar * rs;
+                            const double ydiff = ytil[qi] - fmean;
+                            const double mu = fmean + k * ydiff;
+                            const double omk = 1.0 - k;
+                            const double sig = omk * omk * fvar + k * k * vyt;
+                            const double rf = 1.0 / fvar, rsig = 1.0 / sig;
+                            const double dm = mu - fmean;
+                            // x' = mu + eps sqrt(sig);  kl = .5[log fvar - log sig + (sig + dm^2)/fvar - 1]
+                            const double gmu = gout + a.cL * dm * rf;
+                            const double gsg = gout * eps_t * 0.5 * sqrt(rsig) + a.cL * 0.5 * (rf - rsig);
+                            gfm = -a.cL * dm * rf;
+                            gfv = a.cL * 0.5 * (rf - (sig + dm * dm) * rf * rf);
+                            // mu = fmean + k (ytil - fmean)
+                            gfm += gmu * omk;
+                            double gk = gmu * ydiff;
+                            const double gyt = gmu * k;
+                            // sig = (1-k)^2 fvar + k^2 vyt
+                            gk += gsg * (-2.0 * omk * fvar + 2.0 * k * vyt);
+                            gfv += gsg * omk * omk;
+                            double gvyt = gsg * k * k;
+                            // k = fvar / s ; s = vyt + fvar ; vyt = vy + (kf-1) fvar
+                            gfv += gk * rs;
+                            const double gs = -gk * k * rs;
+                            gvyt += gs;
+                            gfv += gs;
+                            gvy[qi] += gvyt;
+                            gfv += kf1 * gvyt;
+                            if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = gyt;
                         } else {
-                            // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
-                            const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
-                            const double gtot = gout + (write ? gy2in[qi] : 0.0);
-                            gfm = gtot;
-                            gfv = gtot * eps_t * 0.5 / sqrt(fvar) - (write ? a.cE * 0.5 / fvar : 0.0);
+                            // x' = fmean + eps sqrt(fvar), no KL term                           (cbfssm.py:224,234)
+                            gfm = gout;
+                            gfv = gout * eps_t * 0.5 / sqrt(fvar);
+                            if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
                         }
-                        gvx[qi] += gfv;
-                        gsig += gfv;
+                    } else {
+                        // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
+                        const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
+                        const double gtot = gout + (write ? gy2in[qi] : 0.0);
+                        gfm = gtot;
+                        gfv = gtot * eps_t * 0.5 / sqrt(fvar) - (write ? a.cE * 0.5 / fvar : 0.0);
                     }
-                    gdir[qi] = gfm;
-                    if (d < 16) {
-                        Fm[d * PD + nl] = gfm;
-                        Fv[d * PD + nl] = gfv;
-                    }
+                    gvx[qi] += gfv;
+                    gsig += gfv;
+                }
+                gdir[qi] = gfm;
+                if (d < 16) {
+                    Fm[d * PD + nl] = gfm;
+                    Fv[d * PD + nl] = gfv;
                 }
             }
+        }
     };
 
     CBF_STAMP_DECL;
@@ -442,9 +445,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                     for (int s = 0; s < DK; ++s) e = CBF_MFMA(a.pk.Zp[(rbs[i] * DK + s) * 64 + l], bx[s], e);
                 } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) e[r] = tile.czr[i][r] - 0.5 * xx;
+                    for (int r = 0; r < 4; ++r) e[r] = tile.czr[i][r] - 0.5 * xx;
 #pragma unroll
-                for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[i][s], bx[s], e);
+                    for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[i][s], bx[s], e);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         }
         CBF_STAMP_BARRIER(1);
 
-        // ---- C: A2 rows of this wave, P1/P2
+        // ---- C: A2 rows of this wave (only when the forward evaluation did not keep them)
         CBF_STAMP_MARK0();
         if (!a.a2s) {
             d4 acc[RB][2];
@@ -716,10 +719,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                     }
             } else {
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+                for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    ebar[i][r] = (acc[i][0][r] + acc[i][1][r] - a2[i][r] * fvsum) * kreg[i][r];
+                    for (int r = 0; r < 4; ++r)
+                        ebar[i][r] = (acc[i][0][r] + acc[i][1][r] - a2[i][r] * fvsum) * kreg[i][r];
             }
         }
         CBF_STAMP_MARK(6);
