@@ -85,6 +85,7 @@ def test_train_step_decreases_loss_and_matches_tf_adam_rule():
 ])
 def test_hip_train_tail_equals_tensor_library_tail(kw, monkeypatch):
     """cbfssm_train_tail_f64 (five launches) against the same adjoint written with torch ops (CBFSSM_TORCH_TAIL=1)."""
+    monkeypatch.delenv('CBFSSM_TORCH_TAIL', raising=False)
     w = syn.tiny(loss_factors=(2., 0.4), **kw)
     cfg = w.model_config()
     p = {k: torch.tensor(v, device=DEV) for k, v in syn.perturb_params(syn.make_params(w, seed=3), scale=0.1).items()}
