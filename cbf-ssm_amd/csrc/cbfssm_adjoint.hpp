@@ -781,7 +781,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         }
 #pragma unroll
         for (int k2 = 0; k2 < GPW; ++k2) {
-            const int gi = w + k2 * W;
+            // (with four or more waves the later rounds start at the last wave: waves 0-3 also carry phase D; with fewer,
+            //  the groups gi < 4 of later rounds must stay on the wave that owns their phase-D lanes)
+            const int gi = (k2 == 0 || W < 4) ? (w + k2 * W) : (k2 * W + (W - 1 - w));
             if (gi < NG) {
                 const int jb = gi >> 2, q = gi & 3;
                 const int j = 16 * jb + 4 * q + g;
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     }
 #pragma unroll
     for (int k2 = 0; k2 < GPW; ++k2) {
-        const int gi = w + k2 * W;
+        const int gi = (k2 == 0 || W < 4) ? (w + k2 * W) : (k2 * W + (W - 1 - w));
         double v = glx[k2];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
