@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     double auxl[AUXR];
 #pragma unroll
     for (int k2 = 0; k2 < AUXR; ++k2) {
-        const int i = tid + k2 * NT, ja = i >> 4, n = i & 15;
+        const int i = (NT - 1 - tid) + k2 * NT, ja = i >> 4, n = i & 15;   // from the last wave down: waves 0-3 carry D/G
         auxp[k2] = nullptr; auxs[k2] = 0; auxl[k2] = 0.0;
         if (i < 16 * naux) {
             const int b = min(c0 + n, N - 1) / S;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         }
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
-            const int i = tid + k2 * NT;
+            const int i = (NT - 1 - tid) + k2 * NT;
             if (i < 16 * naux) xb[(Do + (i >> 4)) * PD + (i & 15)] = av[k2];
         }
     };
