@@ -592,7 +592,16 @@ static int check_problem(const cbfssm_problem* p, const cbfssm_pack_layout* L, i
 // chains to still cover the chip (every K^-1 operand then feeds two MFMAs and every barrier covers twice the work)
 static int pass_nc(const cbfssm_problem* p, int mode)
 {
-    if (p->ngroups > 0) return 1; // chain-group split is in units of 16 chains
+    if (p->ngroups > 0) {
+        // chain-group split (units of 16 chains): the two-block kernels need an even range; only the skewed backward
+        // runs are worth it there
+        const bool even = ((p->group0 | p->ngroups) & 1) == 0;
+        const int64_t nn = int64_t(p->ngroups) * 16;
+        // (measured at C3, 256 + 64 groups: the skewed kernel on the even main piece is no faster than the one-block
+        //  kernel there -- train 13.84 vs 13.73 ms, eval 4.08 vs 3.89 -- so it is opt-in: CBFSSM_NC_BWD=2)
+        const char* e2 = getenv("CBFSSM_NC_BWD");
+        return (e2 && atoi(e2) == 2 && even && mode == MODE_BWD && !p->half && p->M <= 112 && nn >= 32 * 128) ? 2 : 1;
+    }
     const int64_t n = int64_t(p->B) * p->S;
     const char* e = getenv(mode == MODE_FWD ? "CBFSSM_NC_FWD" : "CBFSSM_NC_BWD");
     // tile heights 13..16 (two row blocks per wave): two column blocks share every streamed K^-1 operand load; their
@@ -621,7 +630,11 @@ static int group_range(const cbfssm_problem* p, int nc, int* g0, int* ng, int* g
     *gt = int((n + 16 * cols - 1) / (16 * cols));
     if (p->ngroups <= 0) { *g0 = 0; *ng = *gt; return 0; }
     if (p->group0 < 0 || p->group0 + p->ngroups > total16) return fail(-1, "bad chain-group range [%d, +%d) of %d", p->group0, p->ngroups, total16);
-    if (nc != 1) return fail(-1, "internal: chain-group split needs the one-group kernels");
+    if (nc != 1) {
+        if ((p->group0 | p->ngroups) & 1) return fail(-1, "internal: an odd chain-group range needs the one-group kernels");
+        *g0 = p->group0 / 2; *ng = p->ngroups / 2;
+        return 0;
+    }
     *g0 = p->group0; *ng = p->ngroups;
     return 0;
 }

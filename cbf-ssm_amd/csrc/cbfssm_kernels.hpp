@@ -659,7 +659,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         const int lo = (k > 1) ? (P * (k - 1) - o) : 0;
         t_first = hi; nsteps = hi - lo + 1; dir = -1;
         if (nsteps <= 0) {
-            if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = 0.0;
+            if (tid == 0) {   // partial sums are indexed per 16-chain group, whatever the kernel variant
+                const int G16p = (a.N + 15) >> 4;
+                for (int cq = 0; cq < NC; ++cq)
+                    if (gx * NC + cq < G16p) a.part_out[blockIdx.y * G16p + gx * NC + cq] = (cq == 0) ? 0.0 : 0.0;
+            }
             return;
         }
     }
@@ -876,7 +880,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         }
     }
     const double tot = block_sum(v, red, tid, NT);
-    if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = tot;
+    if (tid == 0) {   // partial sums are indexed per 16-chain group, whatever the kernel variant
+        const int G16p = (a.N + 15) >> 4;
+        for (int cq = 0; cq < NC; ++cq)
+            if (gx * NC + cq < G16p) a.part_out[blockIdx.y * G16p + gx * NC + cq] = (cq == 0) ? tot : 0.0;
+    }
 #ifdef CBF_REV_STAMPS
     if (a.dbg && l == 0 && (w == 0 || w == W - 1)) {
         double* o = a.dbg + (int64_t(blockIdx.y) * a.gtotal + gx) * 64 + (w == 0 ? 0 : 32);
@@ -928,7 +936,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
         const int lo = (k > 1) ? (P * (k - 1) - o) : 0;
         t_first = hi; nsteps = hi - lo + 1; dir = -1;
         if (nsteps <= 0) {
-            if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = 0.0;
+            if (tid == 0) {   // partial sums are indexed per 16-chain group, whatever the kernel variant
+                const int G16p = (a.N + 15) >> 4;
+                for (int cq = 0; cq < 2; ++cq)
+                    if (gx * 2 + cq < G16p) a.part_out[blockIdx.y * G16p + gx * 2 + cq] = (cq == 0) ? 0.0 : 0.0;
+            }
             return;
         }
     }
@@ -1160,7 +1172,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
             }
         }
     const double tot = block_sum(v, red, tid, NT);
-    if (tid == 0) a.part_out[blockIdx.y * a.gtotal + gx] = tot;
+    if (tid == 0) {   // partial sums are indexed per 16-chain group, whatever the kernel variant
+        const int G16p = (a.N + 15) >> 4;
+        for (int cq = 0; cq < 2; ++cq)
+            if (gx * 2 + cq < G16p) a.part_out[blockIdx.y * G16p + gx * 2 + cq] = (cq == 0) ? tot : 0.0;
+    }
 }
 
 }  // namespace cbfssm

@@ -1,5 +1,6 @@
 """world_size-2 gloo tests (CPU) of the N>1 host path: shard arithmetic, the flat all-reduce helper, identical
 iteration order on every rank.  The sharded-vs-global equality of the kernels themselves is test_distributed_gpu.py."""
+import datetime
 import os
 import socket
 import numpy as np
@@ -33,7 +34,7 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         # one flat float64 buffer per step: [slab_f | slab_b | scalars]
         t = torch.arange(1000, dtype=torch.float64) * (rank + 1)

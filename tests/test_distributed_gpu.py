@@ -1,6 +1,7 @@
 """Two ranks sharing the one GPU of the test box (gloo moves the flat buffer through host memory): the sharded
 train step -- per-rank kernels, ONE all-reduce, prior KL added once -- equals the single-process evaluation of the
 global batch bit-for-bit up to summation order (rel 1e-10)."""
+import datetime
 import os
 import socket
 import numpy as np
@@ -29,7 +30,7 @@ def _case():
 def _worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         from cbfssm.hip import train
         from cbfssm.hip.dist_utils import shard_range
