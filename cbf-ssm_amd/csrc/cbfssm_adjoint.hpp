@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     // while step s computes and lands in the other xq buffer; the epilogue adjoint of step s+1 (phase D) follows phase
     // G of step s in the same lanes, so a step has four workgroup barriers and no load latency on its critical path.
     auto t_of = [&](int step) -> int { return (MODE == MODE_FWD) ? (a.t_hi - step) : (t_begin + step); };
+    int tmod = (MODE == MODE_BWD) ? (t_begin % P) : 0;          // t mod 2R of the step being processed (backward runs)
     // auxiliary input rows of this thread: base pointer, time stride and 1/lengthscale, fixed for the whole pass
     const double* auxp[AUXR];
     int auxs[AUXR];
@@ -241,9 +242,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             auxl[k2] = a.pk.invl[Do + ja];
         }
     }
-    auto load_inputs = [&](int t, double (&hv)[QPW], double (&av)[AUXR]) {
+    // (tm = t mod 2R is carried along the steps: a runtime modulo per step costs ~30 VALU instructions a wave)
+    auto load_inputs = [&](int t, int tm, double (&hv)[QPW], double (&av)[AUXR]) {
         bool rs = false;
-        if (MODE == MODE_BWD) rs = (((t + 1 + run * R) % P) == 0);                            // cbfssm.py:124,127
+        if (MODE == MODE_BWD) rs = (tm + 1 + run * R == P);           // (t + 1 + run R) mod 2R == 0   cbfssm.py:124,127
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             const int d = 4 * (w + qi * W) + g;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             }
         }
     };
-    auto epilogue_adjoint = [&](int t, const double eps_t, const double (&ytil)[QPW], const double (&fmv_m)[QPW],
+    auto epilogue_adjoint = [&](int t, int tm, const double eps_t, const double (&ytil)[QPW], const double (&fmv_m)[QPW],
                                 const double (&fmv_v)[QPW]) {
         const double (&gy2in)[QPW] = ytil;
 #pragma unroll
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                         }
                     } else {
                         // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
-                        const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
+                        const bool write = (run == 0) ? (tm < R) : (tm >= R);
                         const double gtot = gout + (write ? gy2in[qi] : 0.0);
                         gfm = gtot;
                         gfv = gtot * eps_t * 0.5 / sqrt(fvar) - (write ? a.cE * 0.5 / fvar : 0.0);
@@ -383,11 +385,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     double hcur[QPW];
     if (nsteps > 0) {
         double av[AUXR];
-        load_inputs(t_of(0), hcur, av);
+        load_inputs(t_of(0), tmod, hcur, av);
         store_inputs(xq, hcur, av);
         double e0, y0[QPW], m0[QPW], v0[QPW];
         epilogue_load(t_of(0), e0, y0, m0, v0);
-        epilogue_adjoint(t_of(0), e0, y0, m0, v0);
+        epilogue_adjoint(t_of(0), tmod, e0, y0, m0, v0);
     }
     __syncthreads();
     CBF_STAMP_START();
@@ -401,11 +403,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         double* xq = xq0 + (step & 1) * (4 * DK * PD);          // this step's scaled inputs
         double* xqn = xq0 + ((step + 1) & 1) * (4 * DK * PD);   // filled for the next step during this one
         bool resample_t = false;
-        if (MODE == MODE_BWD) resample_t = (((t + 1 + run * R) % P) == 0);                    // cbfssm.py:124,127
+        const int tmn = (tmod + 1 == P) ? 0 : tmod + 1;             // (t + 1) mod 2R: the backward-run adjoint walks t upwards
+        if (MODE == MODE_BWD) resample_t = (tmod + 1 + run * R == P);                         // cbfssm.py:124,127
 
         // next step's inputs: issued now, written to LDS after the kernel tile
         double hnext[QPW], auxn[AUXR];
-        if (has_next) load_inputs(tn, hnext, auxn);
+        if (has_next) load_inputs(tn, tmn, hnext, auxn);
         // A2 rows of this wave, if the forward evaluation kept them (consumed after the second barrier)
         d4 a2[RB];
         if (a.a2s) {
@@ -829,11 +832,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         // ---- D of the next step: same lanes as the carried adjoint just produced (Fm/Fv were last read in phase E)
         CBF_STAMP_MARK0();
         if (has_next) {
-            epilogue_adjoint(tn, eps_n, ytil_n, fm_n, fv_n);
+            epilogue_adjoint(tn, tmn, eps_n, ytil_n, fm_n, fv_n);
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) hcur[qi] = hnext[qi];
         }
         CBF_STAMP_MARK(3);
+        tmod = tmn;
         CBF_STAMP_BARRIER(6);
     }
 

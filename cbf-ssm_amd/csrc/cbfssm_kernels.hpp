@@ -725,6 +725,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     for (int i = tid; i < NC * XS; i += NT) xq[i] = 0.0;
     __syncthreads();
     const bool resample0 = (MODE == MODE_BWD) && (((t_first + 1 + run * R) % P) == 0);
+    const int tm0 = (MODE == MODE_BWD) ? (t_first % P) : 0;
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
         const int d = 4 * qv[qi] + g;
@@ -758,13 +759,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     for (int step = 0; step < nsteps; ++step) {
         const int t = t_first + dir * step;
         const int tn = t + dir;                       // time index of the next GP input
+        // t mod 2R and (t - 1) mod 2R without a runtime modulo per step (a segment has at most 2R steps)
+        int tmod = tm0 - step; if (tmod < 0) tmod += P;
+        const int tmn = (tmod == 0) ? P - 1 : tmod - 1;
         const bool has_next = (step + 1 < nsteps);
         CBF_STAMP_BARRIER(0);                         // xq complete
 
         // ---- prefetch this step's epilogue inputs and the next step's auxiliary rows
         double eps_t[QPW], ytil[QPW], hidn[QPW];
         bool resample_n = false;
-        if (MODE == MODE_BWD) resample_n = has_next && (((tn + 1 + run * R) % P) == 0);     // cbfssm.py:124,127
+        if (MODE == MODE_BWD) resample_n = has_next && (tmn + 1 + run * R == P);            // cbfssm.py:124,127
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             const int c = cc[qi];
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                         if (cval[qi]) a.x_out[(int64_t(t + 1) * N + c) * a.dim_x + d] = outv;       // :229
                     } else {
                         outv = fmean + eps_t[qi] * sqrt(fvar);                         // cbfssm.py:150
-                        const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);             // :125,128
+                        const bool write = (run == 0) ? (tmod < R) : (tmod >= R);             // :125,128
                         if (cval[qi]) {
                             if (write) {
                                 a.y2_out[(int64_t(t) * N + c) * Do + d] = outv;        // :151
@@ -1000,6 +1004,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
     for (int i = tid; i < 2 * XS; i += NT) xq[i] = 0.0;
     __syncthreads();
     const bool resample0 = (MODE == MODE_BWD) && (((t_first + 1 + run * R) % P) == 0);
+    const int tm0 = (MODE == MODE_BWD) ? (t_first % P) : 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int wq = (c == 0) ? w : (W - 1 - w);
@@ -1035,11 +1040,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
         constexpr int c = decltype(cidx)::value;
         const int t = t_first + dir * s;
         const int tn = t + dir;
+        int tmod = tm0 - s; if (tmod < 0) tmod += P;      // t mod 2R, (t - 1) mod 2R (a segment has at most 2R steps)
+        const int tmn = (tmod == 0) ? P - 1 : tmod - 1;
         const bool has_next = (s + 1 < nsteps);
         const int wq = (c == 0) ? w : (W - 1 - w);
         const int cch = cc[c];
         bool resample_n = false;
-        if (MODE == MODE_BWD) resample_n = has_next && (((tn + 1 + run * R) % P) == 0);
+        if (MODE == MODE_BWD) resample_n = has_next && (tmn + 1 + run * R == P);
         double eps_t, hidn = 0.0;
         if (MODE == MODE_FWD) eps_t = a.eps[int64_t(t) * N + cch];
         else {
@@ -1091,7 +1098,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
                         if (cval[c]) a.x_out[(int64_t(t + 1) * N + cch) * a.dim_x + d] = outv;
                     } else {
                         outv = fmean + eps_t * sqrt(fvar);
-                        const bool write = (run == 0) ? ((t % P) < R) : ((t % P) >= R);
+                        const bool write = (run == 0) ? (tmod < R) : (tmod >= R);
                         if (cval[c]) {
                             if (write) {
                                 a.y2_out[(int64_t(t) * N + cch) * Do + d] = outv;
