@@ -658,9 +658,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                         :
                         : "scc", "memory");
                 }
-                for (int s = 4 * nquad; s < KSr; ++s) {             // the 0..3 k-steps left
-                    const double bt = A2t[(4 * s + g) * PD + nl];
-                    acc[0][s & 1] = CBF_MFMA(bop[0][s * 64], bt, acc[0][s & 1]);
+                {   // the 0..3 k-steps left (static accumulator indices: a runtime one makes the compiler index registers)
+                    const int s0 = 4 * nquad, rem = KSr - s0;
+                    if (rem > 0) acc[0][0] = CBF_MFMA(bop[0][s0 * 64], A2t[(4 * s0 + g) * PD + nl], acc[0][0]);
+                    if (rem > 1) acc[0][1] = CBF_MFMA(bop[0][(s0 + 1) * 64], A2t[(4 * s0 + 4 + g) * PD + nl], acc[0][1]);
+                    if (rem > 2) acc[0][0] = CBF_MFMA(bop[0][(s0 + 2) * 64], A2t[(4 * s0 + 8 + g) * PD + nl], acc[0][0]);
                 }
             } else if constexpr (BLDS) {
                 int s = 0;
