@@ -55,6 +55,14 @@ def _unpack_c(v, nrb, ncb):
     return v.view(nrb, ncb, 4, 4, 16).permute(0, 2, 3, 1, 4).reshape(16 * nrb, 16 * ncb)
 
 
+def _stash_contract(gB, sa, sk, Mp, cols):
+    """gB += A K^T over the stashed columns: one float64 library GEMM.  Its kernel choice depends on the shape: at
+    Mp = 208 it ran at 38 TFLOP/s for K = 524 288 and 983 040 columns but at 1.2 TFLOP/s for K = 32 768, 131 072 and
+    327 680 (22.8 ms instead of 0.7 ms) -- the default stash budget keeps the launches in the first regime; a
+    hand-written split-K kernel would remove the dependence (Next)."""
+    gB.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
+
+
 class HipElboGrad:
     """loss and d loss / d (12 unconstrained tensors) for one mini-batch on one device."""
 
@@ -71,7 +79,7 @@ class HipElboGrad:
         self.has_adjoint = all(pk.layout.rev_slab > 0 for pk in (self.pack_f, self.pack_b))
         # tile heights above 112 inducing points run the adjoint in "stash mode" (include/cbfssm_hip.h)
         self.stash = bool(self.pack_f.layout.rev_stash)
-        self.stash_bytes = int(float(config.get('adjoint_stash_gib', 4.0)) * 2 ** 30)
+        self.stash_bytes = int(float(config.get('adjoint_stash_gib', os.environ.get('CBFSSM_STASH_GIB', 8.0))) * 2 ** 30)
         self._stash_buf = None
         if require_adjoint:
             self._need_adjoint()
@@ -379,65 +387,101 @@ class HipElboGrad:
 
     def _adjoint_stash(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):
         """Stash-mode adjoint (M > 112): time-chunked launches, every launch followed by one float64 GEMM that
-        contracts the stashed A2bar / K tiles into d loss / d K^-1 (include/cbfssm_hip.h)."""
+        contracts the stashed A2bar / K tiles into d loss / d K^-1 (include/cbfssm_hip.h).
+
+        Two streams: the forward-pass adjoint walks t downwards in chunks on the current stream; a backward-run launch
+        (a range of resample-to-resample segments of both runs) needs the y2 adjoint only for its own time range, so it
+        starts on the side stream as soon as the forward-pass adjoint has passed below that range and fills the CUs the
+        one-workgroup-per-chain-group forward-pass adjoint leaves idle (320 workgroups on 256 CUs at C4)."""
         lib = _l.load()
-        st = _stream()
         pb = C.byref(prob)
         dev = self.device
         f = dict(dtype=torch.float64, device=dev)
         Mp = self.pack_f.layout.Mp
         T, N = prob.T, prob.B * prob.S
         groups = (N + 15) // 16
-        P = 2 * prob.recog_len
-        cols_max = max(groups * 16 * 2 * P, self.stash_bytes // (2 * Mp * 8))
-        if self._stash_buf is None or self._stash_buf[0].numel() < Mp * cols_max:
-            self._stash_buf = (torch.zeros(Mp * cols_max, **f), torch.zeros(Mp * cols_max, **f))
-        sa, sk = self._stash_buf
+        R = prob.recog_len
+        P = 2 * R
+        # half of the stash budget per direction (the two directions are in flight together)
+        cols_f = max(groups * 16, self.stash_bytes // (4 * Mp * 8))
+        cols_b = max(groups * 16 * 2 * P, self.stash_bytes // (4 * Mp * 8))
+        if self._stash_buf is None or self._stash_buf[0].numel() < Mp * cols_f or self._stash_buf[2].numel() < Mp * cols_b:
+            self._stash_buf = (torch.zeros(Mp * cols_f, **f), torch.zeros(Mp * cols_f, **f),
+                               torch.zeros(Mp * cols_b, **f), torch.zeros(Mp * cols_b, **f))
+        sa_f, sk_f, sa_b, sk_b = self._stash_buf
         sf, sb = self.slab_f, self.slab_b
+        nseg = int(lib.cbfssm_bwd_segments(pb))
+        per_b = max(1, cols_b // (groups * 2 * P * 16))
+        overlap = not os.environ.get('CBFSSM_NO_SPLIT')
+        s0 = torch.cuda.current_stream()
+        s1 = self._side_stream() if overlap else s0
+        st0, st1 = C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)
         red[:sf + sb].zero_()
-        tmp = torch.zeros(max(sf, sb), **f)
+        tmp_f, tmp_b = torch.zeros(max(sf, 1), **f), torch.zeros(max(sb, 1), **f)
         gB_f = torch.zeros(Mp, Mp, **f)
         gB_b = torch.zeros(Mp, Mp, **f)
-        # forward pass, backwards in time
-        per = max(1, cols_max // (groups * 16))
-        t_hi = T - 2
-        first = True
-        while t_hi >= 0 or first:
-            first = False
-            t_lo = max(0, t_hi - per + 1)
-            cols = groups * max(0, t_hi - t_lo + 1) * 16
-            rc = lib.cbfssm_forward_pass_bwd_ex_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
-                                                    _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
-                                                    _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x),
-                                                    _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f),
-                                                    t_hi, t_lo, _ptr(ws.gx_carry),
-                                                    _ptr(sa), _ptr(sk), cols, st)
-            _l.check(rc, 'cbfssm_forward_pass_bwd_ex_f64')
-            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp[:sf]), st), 'reduce f')
-            red[:sf] += tmp[:sf]
-            if cols:
-                gB_f.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
-            t_hi = t_lo - 1
-            if t_hi < 0:
-                break
-        # both backward runs, a range of resample-to-resample segments per launch
-        nseg = int(lib.cbfssm_bwd_segments(pb))
-        per = max(1, cols_max // (groups * 2 * P * 16))
-        seg0 = 0
-        while seg0 < nseg:
-            seg1 = min(nseg, seg0 + per)
+        e_eps = _ptr(eps_f) if eps_f.numel() else None
+        if overlap:
+            s1.wait_stream(s0)                               # the forward evaluation and the zeroing above
+
+        def rfwd(t_hi, t_lo):
+            """forward-pass adjoint of steps t_hi .. t_lo (descending) in launches that fit the stash, on s0"""
+            per = max(1, cols_f // (groups * 16))
+            while True:
+                lo = max(t_lo, t_hi - per + 1)
+                cols = groups * max(0, t_hi - lo + 1) * 16
+                rc = lib.cbfssm_forward_pass_bwd_ex_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
+                                                        _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
+                                                        e_eps, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2),
+                                                        _ptr(ws.gpart_f), t_hi, lo, _ptr(ws.gx_carry), _ptr(sa_f),
+                                                        _ptr(sk_f), cols, st0)
+                _l.check(rc, 'cbfssm_forward_pass_bwd_ex_f64')
+                ev = torch.cuda.Event()
+                ev.record(s0)                                # gy2[t] is final for every t > lo (and t = 0 once lo = 0)
+                _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp_f[:sf]), st0), 'reduce f')
+                red[:sf] += tmp_f[:sf]
+                if cols:
+                    _stash_contract(gB_f, sa_f, sk_f, Mp, cols)
+                if lo <= t_lo or t_hi < 0:
+                    return ev
+                t_hi = lo - 1
+
+        def rbwd(seg0, seg1):
+            """both backward runs, segments [seg0, seg1), on s1"""
             cols = groups * 2 * (seg1 - seg0) * P * 16
-            rc = lib.cbfssm_backward_pass_bwd_ex_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
-                                                     _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
-                                                     _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.gy2), cE,
-                                                     _ptr(ws.gpart_b),
-                                                     seg0, seg1, 1,
-                                                     _ptr(sa), _ptr(sk), cols, st)
-            _l.check(rc, 'cbfssm_backward_pass_bwd_ex_f64')
-            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, 2 * groups, _ptr(tmp[:sb]), st), 'reduce b')
-            red[sf:sf + sb] += tmp[:sb]
-            gB_b.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
-            seg0 = seg1
+            with torch.cuda.stream(s1):
+                rc = lib.cbfssm_backward_pass_bwd_ex_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
+                                                         _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
+                                                         _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.gy2), cE,
+                                                         _ptr(ws.gpart_b), seg0, seg1, 1, _ptr(sa_b), _ptr(sk_b), cols, st1)
+                _l.check(rc, 'cbfssm_backward_pass_bwd_ex_f64')
+                _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, 2 * groups, _ptr(tmp_b[:sb]), st1), 'reduce b')
+                red[sf:sf + sb] += tmp_b[:sb]
+                _stash_contract(gB_b, sa_b, sk_b, Mp, cols)
+
+        t_hi = T - 2                                         # next forward-pass-adjoint step to process
+        seg1 = nseg
+        done_all = (t_hi < 0)
+        if done_all:
+            rfwd(-1, 0)                                      # T == 1: the launch that only hands out the x_0 adjoints
+        while seg1 > 0:
+            seg0 = max(0, seg1 - per_b)
+            # run 1 reaches furthest down: its segment seg0 starts at max(0, P seg0 - R); the y2 adjoint of time t is
+            # written by forward-pass-adjoint step t - 1 (t = 0: by step 0)
+            tmin = 0 if seg0 <= 0 else max(0, P * seg0 - R)
+            need_lo = max(0, tmin - 1)
+            if not done_all and t_hi >= need_lo:
+                ev = rfwd(t_hi, need_lo)
+                t_hi = need_lo - 1
+                done_all = (t_hi < 0)
+                if overlap:
+                    s1.wait_event(ev)
+            rbwd(seg0, seg1)
+            seg1 = seg0
+        if not done_all:
+            rfwd(t_hi, 0)
+        if overlap:
+            s0.wait_stream(s1)
         return gB_f, gB_b
 
     def _gp_adjoint(self, pack, slab, Z, ls, var, zmean, zvar, Do, gB_stash=None, kl_pack=None):
