@@ -55,12 +55,30 @@ def _unpack_c(v, nrb, ncb):
     return v.view(nrb, ncb, 4, 4, 16).permute(0, 2, 3, 1, 4).reshape(16 * nrb, 16 * ncb)
 
 
-def _stash_contract(gB, sa, sk, Mp, cols):
-    """gB += A K^T over the stashed columns: one float64 library GEMM.  Its kernel choice depends on the shape: at
-    Mp = 208 it ran at 38 TFLOP/s for K = 524 288 and 983 040 columns but at 1.2 TFLOP/s for K = 32 768, 131 072 and
-    327 680 (22.8 ms instead of 0.7 ms) -- the default stash budget keeps the launches in the first regime; a
-    hand-written split-K kernel would remove the dependence (Next)."""
-    gB.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
+class StashContract:
+    """d loss / d K^-1 += A2bar K^T over the operand images a stash-mode launch left in HBM (cbfssm_stash_contract_f64).
+    The result is an MFMA C-layout image [NBLK][NBLK][4][64]; `dense()` gives the (Mp, Mp) matrix."""
+
+    def __init__(self, pack, device):
+        self.pack = pack
+        self.n = pack.layout.NBLK * pack.layout.NBLK * 256
+        self.image = torch.zeros(self.n, dtype=torch.float64, device=device)
+        self.work = None
+
+    def add(self, sa, sk, cols, stream):
+        lib = _l.load()
+        nslots = cols // 16
+        if nslots <= 0:
+            return
+        need = int(lib.cbfssm_stash_contract_work_elems(C.byref(self.pack.layout), nslots))
+        if self.work is None or self.work.numel() < need:
+            self.work = torch.zeros(need, dtype=torch.float64, device=self.image.device)
+        _l.check(lib.cbfssm_stash_contract_f64(C.byref(self.pack.layout), _ptr(sa), _ptr(sk), nslots, _ptr(self.work),
+                                               _ptr(self.image), stream), 'cbfssm_stash_contract_f64')
+
+    def dense(self):
+        nb = self.pack.layout.NBLK
+        return _unpack_c(self.image, nb, nb)
 
 
 class HipElboGrad:
@@ -256,7 +274,7 @@ class HipElboGrad:
             Mp = self.pack_f.layout.Mp
             rc = lib.cbfssm_train_tail_f64(C.byref(self.pl), C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
                                            C.byref(self.pack_b.layout), _ptr(self.pack_b.buf), _ptr(red), _ptr(gB_f),
-                                           _ptr(gB_b), Mp, _ptr(pflat), _ptr(self.cflat), _ptr(self.tail_work),
+                                           _ptr(gB_b), 0, _ptr(pflat), _ptr(self.cflat), _ptr(self.tail_work),
                                            _ptr(self.gflat), st)
             _l.check(rc, 'cbfssm_train_tail_f64')
             return loss, _flat_views(self.gflat, self.pl, self.dim_u), terms
@@ -418,8 +436,11 @@ class HipElboGrad:
         st0, st1 = C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)
         red[:sf + sb].zero_()
         tmp_f, tmp_b = torch.zeros(max(sf, 1), **f), torch.zeros(max(sb, 1), **f)
-        gB_f = torch.zeros(Mp, Mp, **f)
-        gB_b = torch.zeros(Mp, Mp, **f)
+        if getattr(self, '_contract', None) is None:
+            self._contract = (StashContract(self.pack_f, dev), StashContract(self.pack_b, dev))
+        con_f, con_b = self._contract
+        con_f.image.zero_()
+        con_b.image.zero_()
         e_eps = _ptr(eps_f) if eps_f.numel() else None
         if overlap:
             s1.wait_stream(s0)                               # the forward evaluation and the zeroing above
@@ -441,7 +462,7 @@ class HipElboGrad:
                 _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp_f[:sf]), st0), 'reduce f')
                 red[:sf] += tmp_f[:sf]
                 if cols:
-                    _stash_contract(gB_f, sa_f, sk_f, Mp, cols)
+                    con_f.add(sa_f, sk_f, cols, st0)
                 if lo <= t_lo or t_hi < 0:
                     return ev
                 t_hi = lo - 1
@@ -457,7 +478,7 @@ class HipElboGrad:
                 _l.check(rc, 'cbfssm_backward_pass_bwd_ex_f64')
                 _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, 2 * groups, _ptr(tmp_b[:sb]), st1), 'reduce b')
                 red[sf:sf + sb] += tmp_b[:sb]
-                _stash_contract(gB_b, sa_b, sk_b, Mp, cols)
+                con_b.add(sa_b, sk_b, cols, st1)
 
         t_hi = T - 2                                         # next forward-pass-adjoint step to process
         seg1 = nseg
@@ -482,7 +503,7 @@ class HipElboGrad:
             rfwd(t_hi, 0)
         if overlap:
             s0.wait_stream(s1)
-        return gB_f, gB_b
+        return con_f.image, con_b.image
 
     def _gp_adjoint(self, pack, slab, Z, ls, var, zmean, zvar, Do, gB_stash=None, kl_pack=None):
         """Adjoint of gp_prepare (K_mm -> chol -> K^-1, operand scaling, prior KL) given the reduced data slab."""
@@ -497,7 +518,7 @@ class HipElboGrad:
             gB = _unpack_c(slab[o:o + NBLK * NBLK * 256], NBLK, NBLK)[:M, :M]
             o += NBLK * NBLK * 256
         else:
-            gB = gB_stash[:M, :M]
+            gB = _unpack_c(gB_stash, NBLK, NBLK)[:M, :M]           # C-layout image of cbfssm_stash_contract_f64
         gZf = _unpack_c(slab[o:o + NBLK * JB * 256], NBLK, JB)
         o += NBLK * JB * 256
         small = slab[o:o + 128]

@@ -16,7 +16,7 @@ from . import lib as _l
 from . import ops
 from .ops import _ptr, _stream, _f64, tf_forward, GPPack
 from .dist_utils import all_reduce_sum
-from .train import HipElboGrad, LOG2PI
+from .train import HipElboGrad, LOG2PI, StashContract
 
 GP_NAMES = ('f.zeta_pos', 'f.zeta_mean', 'f.zeta_var_unc', 'f.variance_unc', 'f.lengthscales_unc')
 RECOG_NAMES = ('recog.gate_kernel', 'recog.gate_bias', 'recog.cand_kernel', 'recog.cand_bias', 'recog.dense_kernel',
@@ -258,7 +258,10 @@ class HipHalfGrad:
             if self._stash_buf is None or self._stash_buf[0].numel() < Mp * cols_max:
                 self._stash_buf = (torch.zeros(Mp * cols_max, **f), torch.zeros(Mp * cols_max, **f))
             sa, sk = self._stash_buf
-            gB = torch.zeros(Mp, Mp, **f)
+            if getattr(self, '_contract', None) is None:
+                self._contract = StashContract(self.pack_f, dev)
+            self._contract.image.zero_()
+            gB = self._contract.image
             tmp = torch.zeros(sf, **f)
             red[:sf].zero_()
             per = max(1, cols_max // (groups * 16))
@@ -275,7 +278,7 @@ class HipHalfGrad:
                 _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp), st), 'reduce f')
                 red[:sf] += tmp
                 if cols:
-                    gB.addmm_(sa[:Mp * cols].view(Mp, cols), sk[:Mp * cols].view(Mp, cols).T)
+                    self._contract.add(sa, sk, cols, st)
                 t_hi = t_lo - 1
                 if t_hi < 0:
                     break

@@ -55,8 +55,9 @@ struct RevArgs {
     int seg0, seg1;        // bwd: resample-to-resample segments [seg0, seg1) of each run, split over grid.z chunks
     int nchunk;            // bwd: grid.z
     double* gx_carry;      // fwd: (N, dim_x) adjoint of x_{t_lo} handed to the next launch (null: single launch)
-    // stash mode (tile heights whose K^-1-adjoint does not fit the VGPR file): A2bar and K tiles of every step go to
-    // HBM as [Mp][ld] matrices, column = (workgroup * chunk_steps + step) * 16 + chain; one GEMM per launch follows
+    // stash mode (tile heights whose K^-1-adjoint does not fit the VGPR file): the A2bar^T and K^T operand images of
+    // every step go to HBM, [slot = workgroup * chunk_steps + step][NBLK][4][64] doubles each (stash_ld = 16 x slots);
+    // cbfssm_stash_contract_f64 contracts them after the launch
     double* stash_a;
     double* stash_k;
     int64_t stash_ld;
@@ -569,13 +570,17 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                     gS2[i] = CBF_MFMA(a2T[s] * a2T[s], fvT[s], gS2[i]);         // s2bar[m][d] += A2[m][n]^2 Fv[d][n]
                 }
                 if constexpr (STASH) {
-                    // A2bar and K rows of this block, column = (workgroup, step, chain)
-                    const int64_t col = (wg_linear * a.chunk_steps + step) * 16 + nl;
+                    // A2bar^T and K^T of this row block as the MFMA operand images of Kinvbar += A2bar K^T (exactly
+                    // what the in-register variant below feeds its MFMAs): slot = (workgroup, step), per slot and
+                    // row block 4 x 64 doubles each; cbfssm_stash_contract_f64 contracts them after the launch
+                    __builtin_amdgcn_wave_barrier();
+                    const int64_t slot = wg_linear * a.chunk_steps + step;
+                    double* pa = a.stash_a + (slot * NBLK + rbs[i]) * 256 + l;
+                    double* pk = a.stash_k + (slot * NBLK + rbs[i]) * 256 + l;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t row = 16 * rbs[i] + g + 4 * r;
-                        a.stash_a[row * a.stash_ld + col] = a2bar[i][r];
-                        a.stash_k[row * a.stash_ld + col] = kreg[i][r];
+                    for (int s = 0; s < 4; ++s) {
+                        pa[s * 64] = own[nl * PD + 4 * s + g];                               // A[row m][k = chain]
+                        pk[s * 64] = Kt[(16 * rbs[i] + nl) * PD + 4 * s + g];                // B[k = chain][col m]
                     }
                 } else {
                     __builtin_amdgcn_wave_barrier();
@@ -869,17 +874,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         }
     }
     if constexpr (STASH) {
-        // unused step slots of this workgroup's column range must read as zero in the GEMM
+        // unused step slots of this workgroup's range must read as zero in the contraction
         for (int step = nsteps; step < a.chunk_steps; ++step) {
-            const int64_t col = (wg_linear * a.chunk_steps + step) * 16 + nl;
+            const int64_t slot = wg_linear * a.chunk_steps + step;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 if (ok[i]) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t row = 16 * rbs[i] + g + 4 * r;
-                        a.stash_a[row * a.stash_ld + col] = 0.0;
-                        a.stash_k[row * a.stash_ld + col] = 0.0;
+                    for (int s = 0; s < 4; ++s) {
+                        a.stash_a[(slot * NBLK + rbs[i]) * 256 + s * 64 + l] = 0.0;
+                        a.stash_k[(slot * NBLK + rbs[i]) * 256 + s * 64 + l] = 0.0;
                     }
                 }
             }

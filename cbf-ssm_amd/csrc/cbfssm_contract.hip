@@ -1,0 +1,164 @@
+// Stash-mode contraction  Kinvbar += sum over (workgroup, step) slots of  A2bar K^T   (cbfssm_adjoint.hpp, STASH).
+//
+// The adjoint kernels of the tall tiles (M > 112) cannot keep the M x M accumulator of d loss / d K^-1 in registers; they
+// write, per step, the two MFMA operand images the in-register variant would have consumed (A2bar^T as A operand, K^T as
+// B operand: [slot][NBLK][4][64] doubles each).  This kernel is that accumulation as a split-K product: a workgroup of
+// eight waves owns up to eight 16-row blocks of the output (one per wave: NBLK accumulator tiles in VGPRs) and a
+// contiguous range of slots; the B image of a slot is shared through LDS (double-buffered), the A image of the wave's
+// row block comes straight from HBM in 512-byte wave loads.  Partial results leave as C-layout images, summed in a
+// fixed order by a second kernel (no atomics: reproducible).
+//
+// It replaces a float64 library GEMM whose kernel choice depended erratically on the number of stashed columns
+// (measured at Mp = 208: 38 TFLOP/s at K = 524 288 and 983 040, 1.2 TFLOP/s at K = 32 768 ... 327 680).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cbfssm_hip.h"
+
+namespace cbfssm {
+
+int fail(int rc, const char* fmt, ...);   // cbfssm_api.hip
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define CBF_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+constexpr int CONTRACT_WAVES = 8;
+
+template <int NBLK>
+__global__ __launch_bounds__(64 * CONTRACT_WAVES) void stash_contract_kernel(const double* __restrict__ sa,
+                                                                             const double* __restrict__ sk, int64_t nslots,
+                                                                             int64_t slots_per_wg, double* __restrict__ part)
+{
+    constexpr int IMG = NBLK * 256;                     // doubles of one operand image (one slot)
+    constexpr int NT = 64 * CONTRACT_WAVES;
+    constexpr int LPT = (IMG + NT - 1) / NT;            // B-image doubles staged per thread
+    extern __shared__ double lds[];                     // [2][IMG]
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int rb = blockIdx.y * CONTRACT_WAVES + w;
+    const bool valid = rb < NBLK;
+    const int rbc = valid ? rb : NBLK - 1;
+    const int64_t s_begin = int64_t(blockIdx.x) * slots_per_wg;
+    const int64_t s_end = (s_begin + slots_per_wg < nslots) ? s_begin + slots_per_wg : nslots;
+
+    d4 acc[NBLK];
+#pragma unroll
+    for (int cb = 0; cb < NBLK; ++cb) acc[cb] = d4{0, 0, 0, 0};
+
+    if (s_begin < s_end) {
+        // prologue: B image of the first slot -> LDS buffer 0
+        for (int i = tid; i < IMG; i += NT) lds[i] = sk[s_begin * IMG + i];
+        double an[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) an[s] = sa[(s_begin * NBLK + rbc) * 256 + s * 64 + l];
+        for (int64_t slot = s_begin; slot < s_end; ++slot) {
+            const int buf = int(slot - s_begin) & 1;
+            const bool has_next = slot + 1 < s_end;
+            // next slot: B image into registers (stored to the other LDS buffer after this slot's MFMAs), A operands
+            double bn[LPT], ac[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ac[s] = an[s];
+            if (has_next) {
+#pragma unroll
+                for (int k = 0; k < LPT; ++k) {
+                    const int i = tid + k * NT;
+                    bn[k] = (i < IMG) ? sk[(slot + 1) * IMG + i] : 0.0;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) an[s] = sa[((slot + 1) * NBLK + rbc) * 256 + s * 64 + l];
+            }
+            __syncthreads();                             // this slot's B image is complete in lds[buf]
+            const double* Bl = lds + buf * IMG + l;
+#pragma unroll
+            for (int cb = 0; cb < NBLK; ++cb) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[cb] = CBF_MFMA(ac[s], Bl[(cb * 4 + s) * 64], acc[cb]);
+            }
+            if (has_next) {
+                double* Bn = lds + (buf ^ 1) * IMG;      // last read two slots ago: ordered by the barrier above
+#pragma unroll
+                for (int k = 0; k < LPT; ++k) {
+                    const int i = tid + k * NT;
+                    if (i < IMG) Bn[i] = bn[k];
+                }
+            }
+        }
+    }
+    if (valid) {
+        double* o = part + (int64_t(blockIdx.x) * NBLK * NBLK + int64_t(rb) * NBLK) * 256 + l;
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[cb * 256 + r * 64] = acc[cb][r];
+    }
+}
+
+// out[i] += sum_k part[k][i] in a fixed order
+__global__ void contract_reduce_kernel(const double* part, int64_t n, int nsplit, double* out)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += part[int64_t(k) * n + i];
+    out[i] += s;
+}
+
+static int contract_split(int64_t nslots)
+{
+    // ~256 slices (two row groups => ~512 workgroups), at least 8 slots each
+    int64_t n = nslots / 8;
+    if (n > 256) n = 256;
+    if (n < 1) n = 1;
+    return int(n);
+}
+
+template <int NBLK>
+static int launch_contract(const double* sa, const double* sk, int64_t nslots, double* work, double* out, hipStream_t st)
+{
+    const int nsplit = contract_split(nslots);
+    const int64_t per = (nslots + nsplit - 1) / nsplit;
+    const int nrg = (NBLK + CONTRACT_WAVES - 1) / CONTRACT_WAVES;
+    const size_t lds = size_t(2) * NBLK * 256 * sizeof(double);
+    auto k = stash_contract_kernel<NBLK>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return -int(e) - 1000;
+    }
+    hipLaunchKernelGGL(k, dim3(unsigned(nsplit), unsigned(nrg)), dim3(64 * CONTRACT_WAVES), lds, st, sa, sk, nslots, per, work);
+    const int64_t n = int64_t(NBLK) * NBLK * 256;
+    hipLaunchKernelGGL(contract_reduce_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, (const double*)work, n, nsplit,
+                       out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -int(e) - 1000;
+}
+
+}  // namespace cbfssm
+
+using namespace cbfssm;
+
+extern "C" {
+
+int64_t cbfssm_stash_contract_work_elems(const cbfssm_pack_layout* L, int64_t nslots)
+{
+    if (!L || nslots < 0) return -1;
+    return int64_t(contract_split(nslots)) * L->NBLK * L->NBLK * 256;
+}
+
+int cbfssm_stash_contract_f64(const cbfssm_pack_layout* L, const double* stash_a, const double* stash_k, int64_t nslots,
+                              double* work, double* ginv_image, void* stream)
+{
+    if (!L || !stash_a || !stash_k || !work || !ginv_image) return fail(-1, "null pointer");
+    if (!L->rev_stash) return fail(-3, "M=%d does not run in stash mode", L->M);
+    if (nslots <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (L->NBLK) {
+        case 10: rc = launch_contract<10>(stash_a, stash_k, nslots, work, ginv_image, st); break;
+        case 13: rc = launch_contract<13>(stash_a, stash_k, nslots, work, ginv_image, st); break;
+        case 16: rc = launch_contract<16>(stash_a, stash_k, nslots, work, ginv_image, st); break;
+        case 20: rc = launch_contract<20>(stash_a, stash_k, nslots, work, ginv_image, st); break;
+        default: return fail(-3, "no contraction kernel for tile height %d", L->NBLK);
+    }
+    return rc ? fail(rc, "stash contraction launch failed (NBLK=%d rc=%d)", L->NBLK, rc) : 0;
+}
+
+}  // extern "C"

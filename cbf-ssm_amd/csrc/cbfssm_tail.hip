@@ -16,7 +16,8 @@ int fail(int rc, const char* fmt, ...);   // cbfssm_api.hip
 
 struct GpTail {
     const double* slab;       // reduced adjoint slab of this GP (Slab<> layout, cbfssm_adjoint.hpp)
-    const double* gB_dense;   // stash mode: dense K^-1 adjoint [.][gB_ld]; else NULL (C-layout image inside the slab)
+    const double* gB_dense;   // stash mode: K^-1 adjoint, dense [.][gB_ld] or (gB_ld = 0) a C-layout image; else NULL (image
+                              // inside the slab)
     int64_t gB_ld;
     const double* Kinv;       // [M][M]
     const double* Kmm;        // [M][M]
@@ -72,7 +73,7 @@ __device__ __forceinline__ double block_sum_t(double v, double* red, int tid, in
 __device__ __forceinline__ double g_elem(const GpTail& p, int k, int j)
 {
     double v;
-    if (p.gB_dense) v = p.gB_dense[int64_t(k) * p.gB_ld + j];
+    if (p.gB_dense) v = (p.gB_ld > 0) ? p.gB_dense[int64_t(k) * p.gB_ld + j] : c_image(p.gB_dense, p.NBLK, k, j);
     else v = c_image(p.slab + 2 * p.NBLK * 256, p.NBLK, k, j);
     double dot = 0.0;
     for (int d = 0; d < p.Do; ++d) dot = fma(p.zmean[k * p.Do + d], p.zmean[j * p.Do + d], dot);

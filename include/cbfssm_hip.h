@@ -257,6 +257,17 @@ int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_l
 int cbfssm_reduce_partials_f64(double* gpart, int64_t slab, int64_t nwg, double* out, void* stream);
 
 /*
+ * Stash mode (layout->rev_stash, M > 112): the `*_bwd_ex_f64` launches write, per (workgroup, step) slot, the two MFMA
+ * operand images of  d loss / d K^-1 += A2bar K^T  (stash_a: A2bar^T, stash_k: K^T; [slot][NBLK][4][64] doubles each, i.e.
+ * 16 NBLK x stash_ld doubles per buffer with stash_ld = 16 x slots).  This contracts `nslots` slots and ADDS the result to
+ * ginv_image, an MFMA C-layout image [NBLK][NBLK][4][64] (the layout of the in-register variant's slab section; row =
+ * 16 rb + (lane >> 4) + 4 r, column = 16 cb + (lane & 15)).  work: cbfssm_stash_contract_work_elems doubles.
+ */
+int64_t cbfssm_stash_contract_work_elems(const cbfssm_pack_layout* layout, int64_t nslots);
+int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* stash_a, const double* stash_k, int64_t nslots,
+                              double* work, double* ginv_image, void* stream);
+
+/*
  * ---- once-per-step tail of a train step ------------------------------------------------------------------------------
  * The twelve trainable tensors of CBFSSM._setup_vars (cbfssm.py:30-58) as ONE flat float64 vector, in this order:
  *   f.zeta_pos (M,D) f.zeta_mean (M,dim_x) f.zeta_var_unc (M,dim_x) f.variance_unc (1) f.lengthscales_unc (D)
@@ -282,8 +293,9 @@ int64_t cbfssm_train_tail_work_elems(const cbfssm_pack_layout* layout_f, const c
  * What tf.gradients (base_model.py:34-36) does after the time loops: the adjoint of GPModel.__init__ / prior_kl
  * (K_mm -> Cholesky -> K^-1, gp_tf.py:33-65,129-130,163-172) for gp_f and gp_b from the reduced adjoint slabs, and the
  * chain through the positivity transforms.  red = [slab_f | slab_b | loglik, kl_x, entropy, dloss/dvar_y[dim_y]] as
- * produced by cbfssm_reduce_partials_f64 (summed over the ranks for a multi-GPU step); gB_dense_*: the dense K^-1
- * adjoints of stash mode (M > 112), NULL otherwise.  Writes d loss / d (flat parameter vector) to gflat.
+ * produced by cbfssm_reduce_partials_f64 (summed over the ranks for a multi-GPU step); gB_dense_*: the K^-1 adjoints
+ * of stash mode (M > 112), NULL otherwise -- dense [.][gB_ld] matrices, or with gB_ld = 0 the C-layout images of
+ * cbfssm_stash_contract_f64.  Writes d loss / d (flat parameter vector) to gflat.
  */
 int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layout* layout_f, const double* pack_f,
                           const cbfssm_pack_layout* layout_b, const double* pack_b, const double* red,
