@@ -229,9 +229,10 @@ int cbfssm_backward_pass_bwd_f64(const cbfssm_problem* p, const cbfssm_pack_layo
 /*
  * General forms of the two adjoint passes: a time range per launch, and "stash mode" for tile heights whose
  * K^-1-adjoint accumulator does not fit the VGPR file (layout->rev_stash == 1, M > 112; the slab then has no
- * d/dK^-1 block).  In stash mode every step writes its A2bar and K tiles to stash_a / stash_k, two [Mp][stash_ld]
- * row-major matrices with column = (workgroup * steps_per_workgroup + step) * 16 + chain, and the caller contracts
- * them afterwards: d loss / d K^-1 += stash_a[:, :cols] @ stash_k[:, :cols]^T  (one plain library GEMM per launch).
+ * d/dK^-1 block).  In stash mode every step writes the two MFMA operand images of d loss / d K^-1 += A2bar K^T to
+ * stash_a / stash_k: [slot][NBLK][4][64] doubles each, slot = workgroup * steps_per_workgroup + step, stash_ld = 16 x
+ * (slots the buffer can hold) -- "columns" below are 16 per slot -- and cbfssm_stash_contract_f64 contracts them after
+ * the launch.
  *   forward:  steps t = t_hi .. t_lo (descending; full pass: T-2 .. 0).  A launch that does not start at T-2 reads the
  *             adjoint of x_{t_hi+1} from gx_carry (N,dim_x); a launch that does not end at 0 writes it there.
  *             columns used: groups * (t_hi - t_lo + 1) * 16.
