@@ -206,6 +206,21 @@ class HipElboGrad:
 
     def loss_and_grads(self, params, u, y, noise, condition=True):
         """params: dict of unconstrained float64 device tensors.  Returns (loss 0-d tensor, grads dict, terms)."""
+        s = self._grads_local(params, u, y, noise, condition)
+        self._grads_collective(s)
+        return self._grads_finish(s)
+
+    # A train step in three parts, so that a data-parallel step can replay the device work on either side of the
+    # collective from HIP graphs (HipTrainStep): everything up to this rank's reduced sums `red`, the all-reduce, the
+    # once-per-step tail.
+    def _grads_collective(self, s):
+        if self.dist is not None:
+            all_reduce_sum(self.red, self.dist)     # the one collective of a train step (RCCL over xGMI)
+            if self.stash:
+                all_reduce_sum(s['gB_f'], self.dist)
+                all_reduce_sum(s['gB_b'], self.dist)
+
+    def _grads_local(self, params, u, y, noise, condition=True):
         self._need_adjoint()
         lib = _l.load()
         dev = self.device
@@ -256,12 +271,16 @@ class HipElboGrad:
         tail = red[sf + sb:]
         _l.check(lib.cbfssm_data_tail_f64(pb, _ptr(c['var_y']), _ptr(ws.ll_part), _ptr(ws.out), cL, _ptr(tail), st),
                  'cbfssm_data_tail_f64')
-        if self.dist is not None:
-            all_reduce_sum(red, self.dist)     # the one collective of a train step (RCCL over xGMI)
-            if self.stash:
-                all_reduce_sum(gB_f, self.dist)
-                all_reduce_sum(gB_b, self.dist)
+        return dict(ws=ws, p=p, c=c, pflat=pflat, gB_f=gB_f, gB_b=gB_b, cL=cL, cE=cE)
 
+    def _grads_finish(self, s):
+        lib = _l.load()
+        dev = self.device
+        st = _stream()
+        ws, p, c, pflat, gB_f, gB_b, cL, cE = (s[k] for k in ('ws', 'p', 'c', 'pflat', 'gB_f', 'gB_b', 'cL', 'cE'))
+        red = self.red
+        sf, sb = self.slab_f, self.slab_b
+        tail = red[sf + sb:]
         loglik, kl_x, entropy = tail[0], tail[1], tail[2]
         kl_z_f, kl_z_b = self.pack_f.scal[_l.SCAL_KLZ], self.pack_b.scal[_l.SCAL_KLZ]
         if self.dist is not None:
@@ -628,17 +647,21 @@ class TFAdam:
 class HipTrainStep:
     """One `sess.run((model.train, model.loss))` (training/trainer.py:40): loss, gradient, Adam update."""
 
-    def __init__(self, config, params, device, dist=None, graph=None):
-        self.engine = HipElboGrad(config, device, dist)
-        p = {k: _f64(params[k], device).clone() for k in PARAM_NAMES}
-        self.opt = TFAdam(p, config['learning_rate'])
+    def __init__(self, config, params, device, dist=None, graph=None, engine=None, opt=None):
+        """Either builds its own engine and optimiser from (config, params), or drives the pair a model object already
+        owns (`engine`, `opt`: cbfssm.model.CBFSSM)."""
+        if engine is None:
+            engine = HipElboGrad(config, device, dist)
+            opt = TFAdam({k: _f64(params[k], device).clone() for k in PARAM_NAMES}, config['learning_rate'])
+        self.engine, self.opt = engine, opt
         self.params = self.opt.views
         # HIP graph: a train step is ~60 launches (kernels of this library + the small torch ops of the once-per-step
         # adjoints and Adam); the small workloads (C1, C2) are launch-bound without it.  One graph per (shapes,
-        # condition), captured at first use.  Not with a process group (the collective stays eager) nor in stash mode.
+        # condition), captured at first use.  Not in stash mode (its launch schedule depends on the stash budget).
         if graph is None:
             graph = config.get('hip_graph', os.environ.get('CBFSSM_HIP_GRAPH', '1') != '0')
-        self.use_graph = bool(graph) and dist is None and not self.engine.stash
+        # With a process group the collective stays eager between two graphs (local part / tail + Adam).
+        self.use_graph = bool(graph) and not self.engine.stash
         self._graphs = {}
 
     def step(self, u, y, noise, condition=True):
@@ -664,21 +687,48 @@ class HipTrainStep:
             with torch.cuda.stream(side):
                 self.engine.loss_and_grads(self.params, g['u'], g['y'], g['noise'], condition)
             cur.wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss, grads, terms = self.engine.loss_and_grads(self.params, g['u'], g['y'], g['noise'], condition)
-                if getattr(grads, 'flat', None) is not None:
-                    self.opt.step(grads)
-                else:
-                    self.opt.step_device(grads)
-                self.opt._t -= 1                  # capture does not execute; every replay counts below
-            g.update(graph=graph, loss=loss, terms=terms)
+            eng = self.engine
+            front = None
+            t_before = self.opt._t
+            try:
+                if eng.dist is not None:
+                    # nothing of the warm-up's collective may still be in flight (its completion polling runs on another
+                    # thread of this process) while the streams are in capture mode
+                    torch.cuda.synchronize(dev)
+                    front = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(front):
+                        state = eng._grads_local(self.params, g['u'], g['y'], g['noise'], condition)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    if front is None:
+                        state = eng._grads_local(self.params, g['u'], g['y'], g['noise'], condition)
+                    loss, grads, terms = eng._grads_finish(state)
+                    if getattr(grads, 'flat', None) is not None:
+                        self.opt.step(grads)
+                    else:
+                        self.opt.step_device(grads)
+                    self.opt._t -= 1              # capture does not execute; every replay counts below
+            except RuntimeError as e:
+                if eng.dist is None:
+                    raise
+                # a data-parallel rank that cannot capture runs the same launches eagerly: the collective sequence is
+                # the same in both modes, so the other ranks are not affected
+                import warnings
+                warnings.warn('HIP graph capture failed on this rank (%s): continuing with eager launches' % e)
+                torch.cuda.synchronize(dev)
+                self.opt._t = t_before
+                self.use_graph = False
+                return self.step(u, y, noise, condition)
+            g.update(graph=graph, front=front, state=state, loss=loss, terms=terms)
             self._graphs[key] = g
         else:
             g['u'].copy_(u)
             g['y'].copy_(y)
             for k in names:
                 g['noise'][k].copy_(_f64(noise[k], dev))
+        if g['front'] is not None:
+            g['front'].replay()
+            self.engine._grads_collective(g['state'])
         g['graph'].replay()
         self.opt._t += 1
         self.last_terms = g['terms']

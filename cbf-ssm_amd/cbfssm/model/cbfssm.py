@@ -119,6 +119,16 @@ class CBFSSM(BaseModel):
 
     _noise_with_backward = True
 
+    def _train_stepper(self):
+        """HipTrainStep over this model's engine and optimiser (CBFSSM only: the variants' recognition networks run in
+        the tensor library's autograd, outside the captured launches)."""
+        from ..hip.train import HipElboGrad, HipTrainStep
+        if type(self._engine) is not HipElboGrad:
+            return None
+        if getattr(self, '_stepper', None) is None or self._stepper.engine is not self._engine:
+            self._stepper = HipTrainStep(self.config, None, self._device, self._dist, engine=self._engine, opt=self._opt)
+        return self._stepper if self._stepper.use_graph else None
+
     def _draw_noise(self, B, T):
         from ..hip.ops import NoisePipeline
         if getattr(self, '_noise', None) is None:
@@ -154,8 +164,13 @@ class CBFSSM(BaseModel):
         noise = self._draw_noise(B, T)
         eng = self._engine
         if 'train' in names:
-            loss, grads, terms = eng.loss_and_grads(self._opt.views, u, y, noise, condition)
-            self._opt.step(grads)                                                                     # cbfssm.py:275
+            stepper = self._train_stepper()
+            if stepper is not None:                       # loss, gradient and Adam update as HIP graph replays
+                loss = stepper.step(u, y, noise, condition)
+                terms = stepper.last_terms
+            else:
+                loss, grads, terms = eng.loss_and_grads(self._opt.views, u, y, noise, condition)
+                self._opt.step(grads)                                                                 # cbfssm.py:275
             ws = eng.last_ws
         else:
             loss, terms, ws = eng.forward(self._opt.views, u, y, noise, condition)

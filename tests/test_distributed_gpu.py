@@ -64,3 +64,45 @@ def test_sharded_step_equals_global_batch():
         assert le == pytest.approx(ref[0], rel=1e-10)
         for k in train.PARAM_NAMES:
             np.testing.assert_allclose(g[k], ref[1][k], rtol=1e-8, atol=1e-9 * np.abs(ref[1][k]).max())
+
+
+def _step_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from cbfssm.hip import train
+        from cbfssm.hip.dist_utils import shard_range
+        w, p, (u, y), noise = _case()
+        lo, hi = shard_range(w.B, rank, world)
+        res = {}
+        for graph in (True, False):
+            st = train.HipTrainStep(w.model_config(), {k: torch.tensor(v, device='cuda:0') for k, v in p.items()},
+                                    'cuda:0', dist, graph=graph)
+            assert st.use_graph == graph
+            losses = []
+            for i in range(3):                                    # fresh inputs every step: the graphs' static copies
+                nz = {'hid_b': noise['hid_b'][:, :, lo:hi] * (1 + i), 'eps_b': noise['eps_b'][:, :, lo:hi],
+                      'eps_f': noise['eps_f'][:, lo:hi] * (1 - 0.1 * i)}
+                nz = {k: np.ascontiguousarray(v) for k, v in nz.items()}
+                losses.append(float(st.step(u[lo:hi] * (1 + 0.01 * i), y[lo:hi], nz)))
+            res[graph] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in st.params.items()})
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_graphs_equal_eager():
+    """With a process group HipTrainStep replays two HIP graphs around the eager all-reduce; losses and parameters after
+    three Adam steps equal the eager data-parallel step bit for bit, and the ranks stay identical."""
+    from cbfssm.hip import train
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_step_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        lg, pg = out[rank][True]
+        le, pe = out[rank][False]
+        assert lg == le
+        for k in train.PARAM_NAMES:
+            np.testing.assert_array_equal(pg[k], pe[k])
+            np.testing.assert_array_equal(pg[k], out[0][True][1][k])
