@@ -238,6 +238,14 @@ def main():
             fa = 2.0 if ws.a2s_b is not None else 3.0
             kern['forward_pass_adjoint'] = (time_kernel(k_rfwd, 5), fa * (w.T - 1) * N * F(w.M, w.D, w.dim_x))
             kern['backward_pass_adjoint'] = (time_kernel(k_rbwd, 5), fa * 2.0 * w.T * N * F(w.M, w.D, w.dim_out_b))
+        # the HBM-bound kernel of the path: log-likelihood + predictive moments, one pass
+        # over the filtered trajectories.  Algorithmic bytes: x and y read once, the four (B,T,.) outputs written once.
+        def k_ll():
+            lib.check(l.cbfssm_loglik_moments_f64(C.byref(prob), ops._ptr(var_y), ops._ptr(y), ops._ptr(ws.x),
+                                                  ops._ptr(ws.ll_part), ops._ptr(ws.pred_mean), ops._ptr(ws.pred_var),
+                                                  ops._ptr(ws.int_mean), ops._ptr(ws.int_var), st), 'loglik')
+        t_ll = time_kernel(k_ll, 20)
+        ll_bytes = 8.0 * (w.T * N * w.dim_x + w.B * w.T * (3 * w.dim_y + 2 * w.dim_x) + ws.ll_part.numel())
         name = max(kern, key=lambda k: kern[k][0])
         tk, fl = kern[name]
         ach = fl / tk / 1e12
@@ -251,6 +259,9 @@ def main():
                 'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'kernel': name,
                 'kernel_ms': {k: v[0] * 1e3 for k, v in kern.items()},
                 'kernel_tflops': {k: v[1] / v[0] / 1e12 for k, v in kern.items()},
+                'hbm_kernel': {'kernel': 'loglik_moments', 'bound': 'hbm', 'ms': t_ll * 1e3,
+                               'achieved': ll_bytes / t_ll / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': ll_bytes / t_ll / 1e9 / HBM_PEAK_GBS},
                 'hbm_algorithmic_GBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9,
                 'hbm_frac_of_8TBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
 

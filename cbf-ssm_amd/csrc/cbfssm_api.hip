@@ -418,32 +418,41 @@ __global__ void loglik_moments_kernel(LlArgs a)
     const int64_t total = int64_t(a.B) * a.T * a.dim_x;
     double ll = 0.0;
     if (idx < total) {
-    const int d = int(idx % a.dim_x);
-    const int64_t bt = idx / a.dim_x;
-    const int t = int(bt % a.T), b = int(bt / a.T);
-    const int64_t N = int64_t(a.B) * a.S;
-    const double* xp = a.x + (int64_t(t) * N + int64_t(b) * a.S) * a.dim_x + d;
-    double sum = 0.0;
-    for (int s = 0; s < a.S; ++s) sum += xp[int64_t(s) * a.dim_x];
-    const double mean = sum / a.S;                                         // tf.nn.moments, cbfssm.py:267
-    double ss = 0.0;
-    for (int s = 0; s < a.S; ++s) {
-        const double dv = xp[int64_t(s) * a.dim_x] - mean;
-        ss += dv * dv;
-    }
-    const double var = ss / a.S;
-    if (a.int_mean) { a.int_mean[idx] = mean; a.int_var[idx] = var; }      // cbfssm.py:269
-    if (d < a.dim_y) {
-        const double vy = a.var_y[d];
-        const int64_t o = bt * a.dim_y + d;
-        a.pred_mean[o] = mean;
-        a.pred_var[o] = var + vy;                                          // cbfssm.py:268
-        // sum_s log N(y | x_s, vy) = -0.5 [ sum_s (y - x_s)^2 / vy + S (log 2 pi + log vy) ]   (cbfssm.py:247-251)
-        const double yo = a.y[o];
-        const double dm = yo - mean;
-        const double sq = ss + a.S * dm * dm;
-        ll = -0.5 * (sq / vy + a.S * (1.8378770664093454836 + log(vy)));
-    }
+        // thread <-> (t, b, d), d fastest, then b: x is (T, N, dim_x), so a wave walks ONE contiguous span of x as it
+        // steps through the particles (S dim_x doubles per (t, b)); the (B, T, .) outputs take the scattered writes,
+        // which are 1/(2S) of the bytes.  (HBM-bound kernel: 8 S dim_x bytes read per 24 bytes written.)
+        const int d = int(idx % a.dim_x);
+        const int64_t tb = idx / a.dim_x;
+        const int b = int(tb % a.B), t = int(tb / a.B);
+        const int64_t bt = int64_t(b) * a.T + t;
+        const int64_t N = int64_t(a.B) * a.S;
+        const double* xp = a.x + (int64_t(t) * N + int64_t(b) * a.S) * a.dim_x + d;
+        // population moments over the particles (tf.nn.moments, cbfssm.py:267) in one pass over HBM: sums of the
+        // differences to the first particle (a shift inside the sample range keeps the cancellation harmless)
+        const double x0 = xp[0];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
+        for (int s = 1; s < a.S; ++s) {
+            const double dv = xp[int64_t(s) * a.dim_x] - x0;
+            s1 += dv;
+            s2 += dv * dv;
+        }
+        const double m1 = s1 / a.S;
+        const double mean = x0 + m1;
+        const double ss = fmax(s2 - s1 * m1, 0.0);                             // sum_s (x_s - mean)^2
+        const double var = ss / a.S;
+        if (a.int_mean) { a.int_mean[bt * a.dim_x + d] = mean; a.int_var[bt * a.dim_x + d] = var; }   // cbfssm.py:269
+        if (d < a.dim_y) {
+            const double vy = a.var_y[d];
+            const int64_t o = bt * a.dim_y + d;
+            a.pred_mean[o] = mean;
+            a.pred_var[o] = var + vy;                                          // cbfssm.py:268
+            // sum_s log N(y | x_s, vy) = -0.5 [ sum_s (y - x_s)^2 / vy + S (log 2 pi + log vy) ]   (cbfssm.py:247-251)
+            const double yo = a.y[o];
+            const double dm = yo - mean;
+            const double sq = ss + a.S * dm * dm;
+            ll = -0.5 * (sq / vy + a.S * (1.8378770664093454836 + log(vy)));
+        }
     }
     sh[threadIdx.x] = ll;
     __syncthreads();
