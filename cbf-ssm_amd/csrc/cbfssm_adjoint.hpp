@@ -82,6 +82,23 @@ struct Slab {
 };
 
 
+// LDS budget of one adjoint workgroup (doubles).  Stash-mode tiles re-read the Z~ operand images every step instead of
+// holding them in registers; when the K^-1 image does not fit anyway, the LDS left over holds those images (a read
+// that misses L1 costs an L2 round trip right in front of the MFMAs that need it).
+template <int NBLK, int RB, int DK, bool STASH>
+struct RevLds {
+    static constexpr int W = (NBLK + RB - 1) / RB;
+    static constexpr int JB = (4 * DK + 1 + 15) / 16;
+    static constexpr int PSL = (JB > 2 ? JB : 2) * 256;
+    static constexpr int BASE = 2 * 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + W * PSL + 64;
+    static constexpr int LIMIT = 163840 / 8;
+    static constexpr int ZP = NBLK * DK * 64 + 16 * NBLK;          // Z~ A-operand image + row constants
+    static constexpr int ZT = NBLK * JB * 256;                     // (Z~)^T A-operand image
+    static constexpr bool ZTLDS = STASH && (BASE + ZT <= LIMIT);
+    static constexpr bool ZLDS = STASH && (BASE + ZP + (ZTLDS ? ZT : 0) <= LIMIT);
+    static constexpr int EXTRA = (ZLDS ? ZP : 0) + (ZTLDS ? ZT : 0);   // used by the variants without the K^-1 image
+};
+
 // BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the ceil(M/4)
 // k-steps that carry data); otherwise it streams from L2.  RB: 16-row blocks of inducing points per wave.
 template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE>
@@ -109,6 +126,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     constexpr int PSL = (JB > 2 ? JB : 2) * 256;
     double* red = part + W * PSL;                       // 64
     double* Bl = red + 64;                              // BLDS: [NBLK][KSr][64]
+    typedef RevLds<NBLK, RB, DK, STASH> RL;
+    constexpr bool ZLDS = RL::ZLDS && !BLDS, ZTLDS = RL::ZTLDS && !BLDS;
+    double* ZTl = red + 64;                             // ZTLDS: [NBLK][JB][4][64]
+    double* Zl = ZTl + (ZTLDS ? NBLK * JB * 256 : 0);   // ZLDS: [NBLK][DK][64] then cz [MP]
+    double* czl = Zl + NBLK * DK * 64;
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
@@ -182,6 +204,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         for (int i = 0; i < RB; ++i)
             if (ok[i])
                 for (int s = 0; s < KSr; ++s) Bl[(rbs[i] * KSr + s) * 64 + l] = a.pk.Bp[(rbs[i] * KS + s) * 64 + l];
+    }
+    if constexpr (ZLDS) {
+        for (int i = tid; i < NBLK * DK * 64; i += NT) Zl[i] = a.pk.Zp[i];
+        for (int i = tid; i < MP; i += NT) czl[i] = a.pk.cz[i];
+    }
+    if constexpr (ZTLDS) {
+        for (int i = tid; i < NBLK * JB * 256; i += NT) ZTl[i] = a.rk.ZT[i];
     }
     const double* bop[RB];
 #pragma unroll
@@ -443,10 +472,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                 if constexpr (STASH) {
                     // (stash mode runs two row blocks per wave at the VGPR cap: the Z~ operand and the row constants
                     //  are re-read from their L1-resident images here instead of living in 40 registers for the pass)
+                    const double* czs = ZLDS ? czl : a.pk.cz;
+                    const double* Zs = ZLDS ? Zl : a.pk.Zp;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) e[r] = a.pk.cz[16 * rbs[i] + 4 * r + g] - 0.5 * xx;
+                    for (int r = 0; r < 4; ++r) e[r] = czs[16 * rbs[i] + 4 * r + g] - 0.5 * xx;
 #pragma unroll
-                    for (int s = 0; s < DK; ++s) e = CBF_MFMA(a.pk.Zp[(rbs[i] * DK + s) * 64 + l], bx[s], e);
+                    for (int s = 0; s < DK; ++s) e = CBF_MFMA(Zs[(rbs[i] * DK + s) * 64 + l], bx[s], e);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) e[r] = tile.czr[i][r] - 0.5 * xx;
@@ -688,9 +719,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                     for (int i = 0; i < RB; ++i)
                         if (ok[i]) acc[i][0] = CBF_MFMA(bop[i][s * 64], b0, acc[i][0]);
                 }
-            } else if constexpr (RB == 2 && NBLK >= 16) {
-                // (measured: -6 % on the C5 step at NBLK = 20; at NBLK = 13 the 48 fixed registers cost more in spills than
-                // the loop gains)
+            } else if constexpr (RB == 2 && NBLK >= 13) {
+                // (measured: -6 % on the C5 step at NBLK = 20, -2 % on the C4 step at NBLK = 13: the loop itself runs 25-30 %
+                // faster, the 48 fixed registers give some of it back as spills in the other phases)
                 // K^-1 streams from L2 through the hand-scheduled loop (cbfssm_kernels.hpp); the image is zero-padded to
                 // KS = 4 NBLK k-steps, the tile rows beyond M are finite, a non-existent second row block is dropped
                 stream_kinv_rb2<4 * PD * 8>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bop[0], bop[1],
@@ -743,7 +774,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 if (ok[i]) {
-                    const double* ZTp = a.rk.ZT + rbs[i] * JB * 256 + l;
+                    const double* ZTp = (ZTLDS ? ZTl : a.rk.ZT) + rbs[i] * JB * 256 + l;
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll

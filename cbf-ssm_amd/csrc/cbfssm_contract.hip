@@ -2,7 +2,7 @@
 //
 // The adjoint kernels of the tall tiles (M > 112) cannot keep the M x M accumulator of d loss / d K^-1 in registers; they
 // write, per step, the two MFMA operand images the in-register variant would have consumed (A2bar^T as A operand, K^T as
-// B operand: [slot][NBLK][4][64] doubles each).  This kernel is that accumulation as a split-K product: a workgroup of
+// B operand: [slot][NBLK][4][64] doubles each).  This kernel is that accumulation as a split-K product: a workgroup of up to
 // eight waves owns up to eight 16-row blocks of the output (one per wave: NBLK accumulator tiles in VGPRs) and a
 // contiguous range of slots; the B image of a slot is shared through LDS (double-buffered), the A image of the wave's
 // row block comes straight from HBM in 512-byte wave loads.  Partial results leave as C-layout images, summed in a
@@ -22,14 +22,23 @@ int fail(int rc, const char* fmt, ...);   // cbfssm_api.hip
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define CBF_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-constexpr int CONTRACT_WAVES = 8;
+// waves per workgroup: eight, or the even split of the row blocks over the same number of workgroups when that drops
+// whole idle waves (every workgroup stages the full B image).  Measured: NBLK = 20 as 3 x 7 instead of 8 + 8 + 4 is
+// -0.8 % on the C5 step; NBLK = 13 as 2 x 7 instead of 8 + 5 is +1.5 % on the C4 step (seven waves load the four SIMDs
+// 2-2-2-1), so odd splits below 16 row blocks stay at eight.
+constexpr int contract_waves(int nblk)
+{
+    const int groups = (nblk + 7) / 8, even = (nblk + groups - 1) / groups;
+    return (nblk < 16 && (even & 1)) ? 8 : even;
+}
 
 template <int NBLK>
-__global__ __launch_bounds__(64 * CONTRACT_WAVES) void stash_contract_kernel(const double* __restrict__ sa,
+__global__ __launch_bounds__(64 * contract_waves(NBLK)) void stash_contract_kernel(const double* __restrict__ sa,
                                                                              const double* __restrict__ sk, int64_t nslots,
                                                                              int64_t slots_per_wg, double* __restrict__ part)
 {
     constexpr int IMG = NBLK * 256;                     // doubles of one operand image (one slot)
+    constexpr int CONTRACT_WAVES = contract_waves(NBLK);
     constexpr int NT = 64 * CONTRACT_WAVES;
     constexpr int LPT = (IMG + NT - 1) / NT;            // B-image doubles staged per thread
     extern __shared__ double lds[];                     // [2][IMG]
@@ -116,6 +125,7 @@ static int launch_contract(const double* sa, const double* sk, int64_t nslots, d
 {
     const int nsplit = contract_split(nslots);
     const int64_t per = (nslots + nsplit - 1) / nsplit;
+    constexpr int CONTRACT_WAVES = contract_waves(NBLK);
     const int nrg = (NBLK + CONTRACT_WAVES - 1) / CONTRACT_WAVES;
     const size_t lds = size_t(2) * NBLK * 256 * sizeof(double);
     auto k = stash_contract_kernel<NBLK>;
