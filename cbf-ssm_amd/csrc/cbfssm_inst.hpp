@@ -49,7 +49,8 @@ int launch_pass_t(const PassArgs& a, dim3 grid, int nc, hipStream_t st)
     typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
     // nc: 1 = one 16-chain column block per workgroup; 2 = two blocks, skewed by half a step (pass_kernel_skew);
     //     3 = two blocks sharing every K^-1 operand load (pass_kernel<NC = 2>: the streamed-K^-1 tiles)
-    const size_t lds = (size_t(nc == 1 ? 1 : 2) * (TT::LDS_DOUBLES - 64) + 64) * sizeof(double);
+    const size_t lds = (size_t(nc == 1 ? 1 : 2) * (TT::LDS_DOUBLES - 64) + 64 + (nc == 1 ? TT::EPI_LDS_DOUBLES : 0)) *
+                       sizeof(double);
     hipError_t e;
     if (nc == 3) {
         auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 2>;

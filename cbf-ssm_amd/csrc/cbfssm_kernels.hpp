@@ -261,6 +261,10 @@ struct Tile {
     static constexpr int KS = MP / 4;                // k-steps of the K^-1 K product
     static constexpr int QPW = (4 + W - 1) / W;      // state-row groups (4 rows each) per wave in phase 3
     static constexpr int LDS_DOUBLES = DK * 64 + MP * 16 + W * 512 + 64;   // per column block (+64 once)
+    // pass_kernel<NC = 1>, streamed K^-1: how many of the mean / variance operand images fit into LDS next to the tiles
+    static constexpr int EPI_LDS_N = BREG ? 0 : (LDS_DOUBLES + 2 * NBLK * 256 <= 20480 ? 2 : (LDS_DOUBLES + NBLK * 256 <= 20480 ? 1 : 0));
+    static constexpr bool EPI_LDS = EPI_LDS_N > 0;
+    static constexpr int EPI_LDS_DOUBLES = EPI_LDS_N * NBLK * 256;
 
     // loop-invariant MFMA A operands of this wave
     double Zreg[RB][DK];
@@ -670,6 +674,19 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 
     TT tile;
     tile.load_operands(a.pk, w, l);
+    if constexpr (TT::EPI_LDS && NC == 1) {
+        // streamed-K^-1 tiles re-read the mean / variance operand images every step: from LDS (100 KB are free next to
+        // the tiles) instead of through an L1 that the K^-1 stream keeps flushing
+        double* mul = red + 64;
+        for (int i = tid; i < NBLK * 256; i += NT) mul[i] = a.pk.muA[i];
+        tile.muAg = mul;
+        if constexpr (TT::EPI_LDS_N == 2) {
+            double* s2l = mul + NBLK * 256;
+            for (int i = tid; i < NBLK * 256; i += NT) s2l[i] = a.pk.s2A[i];
+            tile.s2Ag = s2l;
+        }
+        // (the barrier that publishes the first step's inputs below also orders these writes)
+    }
 
     // per-lane constants of the phase-3 tasks of this wave: task tk = w + qi*W -> (q = tk & 3, column block tk >> 2)
     double vx[QPW], vy[QPW], il[QPW];
