@@ -21,7 +21,15 @@ PY
 python3 bench.py > $OUT/bench_train_C3.json 2> $OUT/bench_train_C3.err
 python3 bench.py --mode eval > $OUT/bench_eval_C3.json 2> $OUT/bench_eval_C3.err
 for w in C1 C2 C4; do python3 bench.py --workload $w --mode train --no-cpu-baseline > $OUT/bench_train_$w.json 2> $OUT/bench_train_$w.err; done
+python3 bench.py --workload C4 --mode eval --no-cpu-baseline > $OUT/bench_eval_C4.json 2> $OUT/bench_eval_C4.err
+python3 bench.py --workload C5 --mode train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_train_C5.json 2> $OUT/bench_train_C5.err
+python3 bench.py --workload C5 --mode eval --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_eval_C5.json 2> $OUT/bench_eval_C5.err
+python3 profiles/tools/dropin_throughput.py > $OUT/dropin_throughput.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 CBFSSM_HIP_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ktrace -o c3 -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/$OUT/ktrace.log 2>&1
 cp $(ls $R/$OUT/ktrace/*kernel_stats.csv | head -1) $R/$OUT/train_C3_kernel_stats.csv
+CBFSSM_HIP_GRAPH=0 CBFSSM_NO_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ktrace_ns -o c3 -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/$OUT/bench_train_C3_nosplit_under_rocprof.json 2> $R/$OUT/ktrace_ns.log
+cp $(ls $R/$OUT/ktrace_ns/*kernel_stats.csv | head -1) $R/$OUT/train_C3_kernel_stats_nosplit.csv
+CBFSSM_HIP_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/ktrace_c4 -o c4 -- python3 $R/bench.py --workload C4 --mode train --steps 4 --warmup 2 --no-cpu-baseline > $R/$OUT/ktrace_c4.log 2>&1
+cp $(ls $R/$OUT/ktrace_c4/*kernel_stats.csv | head -1) $R/$OUT/train_C4_kernel_stats.csv
 ls -la $R/$OUT

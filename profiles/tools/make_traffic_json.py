@@ -42,8 +42,9 @@ res['_note'] = ('bytes per full launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 102
                 'MI355X_MICROARCH.md (HBM) prescribes for coalesced streams: these kernels read 128..512 contiguous bytes '
                 'per wave-instruction (128-B requests tallied at 64 B).  Calibrated on the eval-mode backward pass, whose '
                 'compulsory reads are known (noise 41 MB + u, y 7 MB = 48 MB; FETCH_SIZE reports 22 MB), and on '
-                'loglik_moments_kernel for the opposite case (8-B reads at a 112-B stride: 147 MB compulsory, 156 MB '
-                'reported, no correction).' % wl.replace(':', ' --mode '))
+                'loglik_moments_kernel (147 MB compulsory reads): 156 MB reported while it read 8 B per lane at a 112-B '
+                'stride (no correction applies), 83 MB reported now that a wave reads contiguous 112-B runs (2 x 83 = 166 '
+                'MB: partial 128-B lines make the factor 1.8 rather than 2 there).' % wl.replace(':', ' --mode '))
 try:
     allj = json.load(open(out))
 except Exception:
