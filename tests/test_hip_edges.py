@@ -142,3 +142,35 @@ def test_train_tail_entry_points_through_the_abi():
     sq = (-2.0 * ll_d - bts * (np.log(2 * np.pi) + np.log(vy[:dy]))) * vy[:dy]
     ref_t = np.concatenate([out8[:3], -cL * 0.5 * (sq / vy[:dy] ** 2 - bts / vy[:dy])])
     np.testing.assert_allclose(tail.cpu().numpy(), ref_t, rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize('S', [1, 2, 7, 50])
+def test_loglik_moments_one_pass_keeps_the_digits(S):
+    """cbfssm_loglik_moments_f64 takes the population moments over the particles (tf.nn.moments, cbfssm.py:267) in one
+    pass over HBM (sums of differences to the first particle).  Worst case for a one-pass variance: particles that
+    sit 1e6 spreads away from zero.  Checked against a long-double two-pass evaluation, called through the C ABI."""
+    import ctypes as C
+    l = lib.load()
+    B, T, dx, dy = 3, 5, 6, 2
+    rng = np.random.default_rng(S)
+    x = 1e3 + 1e-3 * rng.standard_normal((T, B, S, dx))                  # (T, N, dim_x) as the forward pass writes it
+    y = 1e3 + rng.standard_normal((B, T, dy))
+    vy = np.abs(rng.standard_normal(dx)) + 0.1
+    prob = lib.make_problem(B, S, T, dx, 1, dy, 8, 2, 1.0, True)
+    f = dict(dtype=torch.float64, device=DEV)
+    tx, ty, tv = torch.tensor(x, **f).contiguous(), torch.tensor(y, **f).contiguous(), torch.tensor(vy, **f)
+    ll = torch.zeros(int(l.cbfssm_loglik_partials(C.byref(prob))), **f)
+    pm, pv = torch.zeros(B, T, dy, **f), torch.zeros(B, T, dy, **f)
+    im, iv = torch.zeros(B, T, dx, **f), torch.zeros(B, T, dx, **f)
+    lib.check(l.cbfssm_loglik_moments_f64(C.byref(prob), ops._ptr(tv), ops._ptr(ty), ops._ptr(tx), ops._ptr(ll),
+                                          ops._ptr(pm), ops._ptr(pv), ops._ptr(im), ops._ptr(iv), None), 'loglik')
+    torch.cuda.synchronize()
+    xl = np.transpose(x, (1, 0, 2, 3)).astype(np.longdouble)             # (B, T, S, dx)
+    mean = xl.mean(axis=2)
+    var = ((xl - mean[:, :, None, :]) ** 2).mean(axis=2)
+    np.testing.assert_allclose(im.cpu().numpy(), mean.astype(np.float64), rtol=1e-15)
+    np.testing.assert_allclose(iv.cpu().numpy(), var.astype(np.float64), rtol=1e-9, atol=1e-30)
+    np.testing.assert_allclose(pv.cpu().numpy(), (var[..., :dy] + vy[:dy]).astype(np.float64), rtol=1e-12)
+    lg = (-0.5 * (((y.astype(np.longdouble)[:, :, None, :] - xl[..., :dy]) ** 2) / vy[:dy]
+                  + np.log(2 * np.pi * vy[:dy].astype(np.longdouble)))).sum()
+    assert float(ll.sum()) == pytest.approx(float(lg), rel=1e-12)
