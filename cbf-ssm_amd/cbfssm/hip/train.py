@@ -690,16 +690,19 @@ class HipTrainStep:
             eng = self.engine
             front = None
             t_before = self.opt._t
+            # with a process group, other threads of this process (the collective library's completion polling) may
+            # touch the runtime while this thread captures: only this thread's calls are checked then
+            mode = 'global' if eng.dist is None else 'thread_local'
             try:
                 if eng.dist is not None:
                     # nothing of the warm-up's collective may still be in flight (its completion polling runs on another
                     # thread of this process) while the streams are in capture mode
                     torch.cuda.synchronize(dev)
                     front = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(front):
+                    with torch.cuda.graph(front, capture_error_mode=mode):
                         state = eng._grads_local(self.params, g['u'], g['y'], g['noise'], condition)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=mode):
                     if front is None:
                         state = eng._grads_local(self.params, g['u'], g['y'], g['noise'], condition)
                     loss, grads, terms = eng._grads_finish(state)
