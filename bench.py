@@ -125,7 +125,11 @@ def main():
 
     red = torch.zeros(8, dtype=torch.float64, device=dev)
     if mode == 'train':
-        stepper = HipTrainStep(cfg, params, dev, dist if world > 1 else None)
+        # N > 1: the data-parallel step can replay two HIP graphs around the eager all-reduce (tests/test_distributed_gpu.py);
+        # at this workload the launches are hidden behind the kernels anyway, so the bench keeps plain launches there
+        # unless asked (CBFSSM_DP_GRAPH=1)
+        use_graph = None if world == 1 else (os.environ.get('CBFSSM_DP_GRAPH') == '1')
+        stepper = HipTrainStep(cfg, params, dev, dist if world > 1 else None, graph=use_graph)
 
         def step():
             return stepper.step(u, y, draw_noise(), condition=True)
