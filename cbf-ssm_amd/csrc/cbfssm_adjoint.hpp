@@ -94,9 +94,12 @@ struct RevLds {
     static constexpr int LIMIT = 163840 / 8;
     static constexpr int ZP = NBLK * DK * 64 + 16 * NBLK;          // Z~ A-operand image + row constants
     static constexpr int ZT = NBLK * JB * 256;                     // (Z~)^T A-operand image
+    static constexpr int MU = NBLK * 256;                          // mu_z B-operand image (phase E)
+    // filled in this order (measured at NBLK = 13 / D = 21, where only part fits: {(Z~)^T} and {Z~, mu} are within 1 %)
     static constexpr bool ZTLDS = STASH && (BASE + ZT <= LIMIT);
     static constexpr bool ZLDS = STASH && (BASE + ZP + (ZTLDS ? ZT : 0) <= LIMIT);
-    static constexpr int EXTRA = (ZLDS ? ZP : 0) + (ZTLDS ? ZT : 0);   // used by the variants without the K^-1 image
+    static constexpr bool MULDS = ZLDS && (BASE + ZP + (ZTLDS ? ZT : 0) + MU <= LIMIT);
+    static constexpr int EXTRA = (ZLDS ? ZP : 0) + (ZTLDS ? ZT : 0) + (MULDS ? MU : 0);   // variants without the K^-1 image
 };
 
 // BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the ceil(M/4)
@@ -127,10 +130,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     double* red = part + W * PSL;                       // 64
     double* Bl = red + 64;                              // BLDS: [NBLK][KSr][64]
     typedef RevLds<NBLK, RB, DK, STASH> RL;
-    constexpr bool ZLDS = RL::ZLDS && !BLDS, ZTLDS = RL::ZTLDS && !BLDS;
+    constexpr bool ZLDS = RL::ZLDS && !BLDS, ZTLDS = RL::ZTLDS && !BLDS, MULDS = RL::MULDS && !BLDS;
     double* ZTl = red + 64;                             // ZTLDS: [NBLK][JB][4][64]
     double* Zl = ZTl + (ZTLDS ? NBLK * JB * 256 : 0);   // ZLDS: [NBLK][DK][64] then cz [MP]
     double* czl = Zl + NBLK * DK * 64;
+    double* mul = Zl + (ZLDS ? RL::ZP : 0);             // MULDS: [NBLK][4][64]
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
@@ -211,6 +215,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     }
     if constexpr (ZTLDS) {
         for (int i = tid; i < NBLK * JB * 256; i += NT) ZTl[i] = a.rk.ZT[i];
+    }
+    if constexpr (MULDS) {
+        for (int i = tid; i < NBLK * 256; i += NT) mul[i] = a.rk.muB[i];
     }
     const double* bop[RB];
 #pragma unroll
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         for (int i = 0; i < RB; ++i) {
             a2bar[i] = d4{0, 0, 0, 0};
             if (ok[i]) {
-                const double* mBp = a.rk.muB + rbs[i] * 256 + l;
+                const double* mBp = (MULDS ? mul : a.rk.muB) + rbs[i] * 256 + l;
                 const double* sBp = a.rk.s2B + rbs[i] * 256 + l;
                 d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
 #pragma unroll
