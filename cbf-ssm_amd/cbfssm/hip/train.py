@@ -737,21 +737,3 @@ class HipTrainStep:
         self.last_terms = g['terms']
         return g['loss'].clone()
 
-
-def train_step_smoke():
-    """Used by __graft_entry__.smoke(): one tiny train step on cuda:0, gradient checked against the CPU oracle."""
-    import numpy as np
-    from cbfssm import synthetic as syn
-    from oracle import cbfssm_torch_ref as tref
-    w = syn.tiny(M=20, T=13, B=2, S=8)
-    cfg = w.model_config()
-    p = syn.perturb_params(syn.make_params(w))
-    u, y = syn.make_inputs(w)
-    noise = syn.make_noise(w)
-    eng = HipElboGrad(cfg, 'cuda:0')
-    loss, grads, _ = eng.loss_and_grads({k: torch.tensor(v, device='cuda:0') for k, v in p.items()}, u, y, noise)
-    scal, gref = tref.loss_and_grads(cfg, p, u, y, noise, True)
-    assert abs(float(loss) - scal['loss']) <= 1e-9 * abs(scal['loss'])
-    for k in PARAM_NAMES:
-        np.testing.assert_allclose(grads[k].cpu().numpy(), gref[k], rtol=1e-6, atol=1e-7 * np.abs(gref[k]).max())
-    print('smoke ok: train-step gradient matches the oracle for all 12 tensors')
