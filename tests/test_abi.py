@@ -54,3 +54,35 @@ def test_param_layout_is_host_only_and_ordered():
             assert False, bad
         except lib.CbfssmHipError:
             pass
+
+
+def test_product_never_imports_the_oracle_and_has_no_fallback(tmp_path, monkeypatch):
+    """oracle/ is test infrastructure: no module of the package (nor a profiling tool) may import it, and a missing
+    shared library is an error, not a reason to compute somewhere else."""
+    import ast
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for top in ('cbf-ssm_amd', os.path.join('profiles', 'tools')):
+        for d, _, files in os.walk(os.path.join(root, top)):
+            for f in files:
+                if not f.endswith('.py'):
+                    continue
+                tree = ast.parse(open(os.path.join(d, f)).read())
+                for node in ast.walk(tree):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or '']
+                    if any(n == 'oracle' or n.startswith('oracle.') for n in names):
+                        offenders.append(os.path.join(d, f))
+    assert not offenders, offenders
+    code = ('import sys; sys.path[:0] = [%r, %r]\n'
+            'from cbfssm.hip import lib\n'
+            'try:\n    lib.load()\nexcept lib.CbfssmHipError as e:\n    print("LOUD:", e)\n'
+            % (root, os.path.join(root, 'cbf-ssm_amd')))
+    env = dict(os.environ, CBFSSM_HIP_LIB=str(tmp_path / 'absent.so'))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=240)
+    assert 'LOUD:' in out.stdout and 'no fallback' in out.stdout, (out.stdout, out.stderr)
