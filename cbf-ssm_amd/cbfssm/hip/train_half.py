@@ -167,7 +167,7 @@ class HipHalfGrad:
             ws.x = torch.zeros(prob.T, N, prob.dim_x, **f)
             ws.fmv_f = torch.zeros(max(prob.T - 1, 0), N, prob.dim_x, 2, **f)
             n_a2 = int(lib.cbfssm_saved_a2_elems(C.byref(prob), C.byref(self.pack_f.layout), 0))
-            keep = 8.0 * n_a2 <= float(os.environ.get('CBFSSM_A2S_MAX_GB', '24')) * 2 ** 30
+            keep = 8.0 * n_a2 <= ops.a2s_budget_bytes(self.device)
             ws.a2s_f = torch.zeros(max(n_a2, 1), **f) if keep else None
             ws.kl_part = torch.zeros(ws.n_kl, **f)
             ws.ll_part = torch.zeros(int(lib.cbfssm_loglik_partials(C.byref(prob))), **f)   # [block][dim_y]
