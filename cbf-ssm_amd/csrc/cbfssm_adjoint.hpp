@@ -90,7 +90,13 @@ struct RevLds {
     static constexpr int W = (NBLK + RB - 1) / RB;
     static constexpr int JB = (4 * DK + 1 + 15) / 16;
     static constexpr int PSL = (JB > 2 ? JB : 2) * 256;
-    static constexpr int BASE = 2 * 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + W * PSL + 64;
+    static constexpr int BASE_PLAIN = 2 * 4 * DK * 17 + 2 * (16 * NBLK) * 17 + 2 * 16 * 17 + W * PSL + 64;
+    // Stash-mode tiles that stream K^-1: the per-wave partial tiles of the input adjoint (`part`, written at the end of
+    // phase F, read in phase G) live in the K tile's LDS, which is dead by then -- one more workgroup barrier per step
+    // buys W x PSL doubles (28 KB at NBLK = 13) for the operand images below.
+    static constexpr bool PALIAS = STASH;
+    static constexpr int KTR = PALIAS ? ((16 * NBLK) * 17 > W * PSL ? (16 * NBLK) * 17 : W * PSL) : (16 * NBLK) * 17;
+    static constexpr int BASE = PALIAS ? 2 * 4 * DK * 17 + KTR + (16 * NBLK) * 17 + 2 * 16 * 17 + 64 : BASE_PLAIN;
     static constexpr int LIMIT = 163840 / 8;
     static constexpr int ZP = NBLK * DK * 64 + 16 * NBLK;          // Z~ A-operand image + row constants
     static constexpr int ZT = NBLK * JB * 256;                     // (Z~)^T A-operand image
@@ -121,15 +127,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
 
     extern __shared__ double lds[];
     double* xq0 = lds;                                  // [2][4*DK][17]: this step's and the next step's inputs
+    typedef RevLds<NBLK, RB, DK, STASH> RL;
+    constexpr bool PALIAS = RL::PALIAS && !BLDS;        // `part` shares the K tile's LDS (see RevLds)
+    constexpr int PSL = (JB > 2 ? JB : 2) * 256;
     double* Kt = xq0 + 2 * 4 * DK * PD;                 // [MP][17]
-    double* A2t = Kt + MP * PD;                         // [MP][17]
+    double* A2t = Kt + (PALIAS ? RL::KTR : MP * PD);    // [MP][17]
     double* Fm = A2t + MP * PD;                         // [16][17]
     double* Fv = Fm + 16 * PD;                          // [16][17]
-    double* part = Fv + 16 * PD;                        // [W][max(2,JB)][4][64]
-    constexpr int PSL = (JB > 2 ? JB : 2) * 256;
-    double* red = part + W * PSL;                       // 64
+    double* part = PALIAS ? Kt : (Fv + 16 * PD);        // [W][max(2,JB)][4][64]
+    double* red = PALIAS ? (Fv + 16 * PD) : (part + W * PSL);   // 64
     double* Bl = red + 64;                              // BLDS: [NBLK][KSr][64]
-    typedef RevLds<NBLK, RB, DK, STASH> RL;
     constexpr bool ZLDS = RL::ZLDS && !BLDS, ZTLDS = RL::ZTLDS && !BLDS, MULDS = RL::MULDS && !BLDS;
     double* ZTl = red + 64;                             // ZTLDS: [NBLK][JB][4][64]
     double* Zl = ZTl + (ZTLDS ? NBLK * JB * 256 : 0);   // ZLDS: [NBLK][DK][64] then cz [MP]
@@ -774,8 +781,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             }
         }
         CBF_STAMP_MARK(6);
+        d4 xp[JB];
         {
-            d4 xp[JB];
 #pragma unroll
             for (int jb = 0; jb < JB; ++jb) xp[jb] = d4{0, 0, 0, 0};
 #pragma unroll
@@ -789,10 +796,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                             xp[jb] = CBF_MFMA(ZTp[(jb * 4 + r) * 64], ebar[i][r], xp[jb]);   // rows j, k = m of this block
                 }
             }
+            if constexpr (!PALIAS) {
 #pragma unroll
-            for (int jb = 0; jb < JB; ++jb)
+                for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
+                    for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
+            }
         }
         CBF_STAMP_MARK(7);
 #pragma unroll
@@ -818,6 +827,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             }
         }
         CBF_STAMP_MARK(8);
+        if constexpr (PALIAS) {
+            __syncthreads();                 // every wave is done with its rows of the K tile (Ebar, the transposes)
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
+        }
         CBF_STAMP_BARRIER(5);
 
         // ---- G: input adjoint, carried to the next reverse step

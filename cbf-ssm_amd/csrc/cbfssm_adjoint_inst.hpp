@@ -41,8 +41,8 @@ int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
         hipLaunchKernelGGL(k, grid, dim3(64 * C::W), lds, st, a);
     } else {
         typedef RevLds<NBLK, C::RB, DK, C::STASH> RL;
-        static_assert(RL::BASE == G::LDS_BASE, "LDS layout");
-        const size_t lds = size_t(G::LDS_BASE + RL::EXTRA) * sizeof(double);
+        static_assert(RL::BASE_PLAIN == G::LDS_BASE, "LDS layout");
+        const size_t lds = size_t(RL::BASE + RL::EXTRA) * sizeof(double);
         auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
