@@ -110,8 +110,18 @@ struct RevLds {
 
 // BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the ceil(M/4)
 // k-steps that carry data); otherwise it streams from L2.  RB: 16-row blocks of inducing points per wave.
+// Seven row-block waves load the four SIMDs 2-2-2-1.  The in-register tiles of that height get an EIGHTH wave, which
+// lands next to wave 3 and takes the last rev_xcb() column blocks of the Kinvbar accumulation for ALL row blocks (its
+// operands, A2bar and K, are complete in the LDS tiles between the barriers that end phases E and F); it has no other
+// role and leaves before the epilogue (a wave that has ended no longer counts at s_barrier).
+// Measured on the C3 kernels (ms, forward-pass / backward-run adjoint; without the wave 5.12 / 5.83):
+//   1 block 5.14 / 5.59, 2 blocks 4.89 / 5.60, 3 blocks 4.81 / 5.72, 4 blocks 5.11 / 6.01 (the extra wave's 112 MFMAs
+//   no longer fit into phase F next to wave 3's own).  The forward-pass adjoint has the longer phase E (14 outputs).
+constexpr int rev_xcb(int mode) { return mode == MODE_FWD ? 3 : 2; }
+constexpr bool rev_extra_wave(int nblk, bool stash) { return nblk == 7 && !stash; }
+
 template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE>
-__global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArgs a)
+__global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, STASH) ? 1 : 0))) void rev_kernel(RevArgs a)
 {
     constexpr bool BREG = false;
     typedef Tile<NBLK, RB, DK, BREG> TT;
@@ -121,7 +131,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     constexpr int GPW = (NG + W - 1) / W;               // groups per wave in phase G
     constexpr int PD = 17;                              // padded row length of the LDS tiles
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
-    constexpr int NCB = STASH ? 1 : NBLK;
+    constexpr bool XW = rev_extra_wave(NBLK, STASH);
+    constexpr int XCB = XW ? rev_xcb(MODE) : 0;         // column blocks of Kinvbar accumulated by the extra wave
+    constexpr int NCB = STASH ? 1 : NBLK - XCB;         // ... and by the wave that owns the row block
     constexpr bool ALL_OK = (NBLK % RB == 0);           // every wave owns RB real row blocks (no predicate around MFMAs)
     typedef Slab<NBLK, JB, STASH> SL;
 
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
     for (int k2 = 0; k2 < AUXR; ++k2) {
         const int i = (NT - 1 - tid) + k2 * NT, ja = i >> 4, n = i & 15;   // from the last wave down: waves 0-3 carry D/G
         auxp[k2] = nullptr; auxs[k2] = 0; auxl[k2] = 0.0;
-        if (i < 16 * naux) {
+        if (i >= 0 && i < 16 * naux) {
             const int b = min(c0 + n, N - 1) / S;
             if (ja < a.dim_u) { auxp[k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[k2] = a.dim_u; }
             else { auxp[k2] = a.y + int64_t(b) * T * a.dim_y + (ja - a.dim_u); auxs[k2] = a.dim_y; }
@@ -425,6 +437,45 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         }
     };
 
+    if constexpr (XW) {
+        if (w == W) {
+            d4 xacc[NBLK][XCB];
+#pragma unroll
+            for (int rb = 0; rb < NBLK; ++rb)
+#pragma unroll
+                for (int cq = 0; cq < XCB; ++cq) xacc[rb][cq] = d4{0, 0, 0, 0};
+            __syncthreads();                                         // (the barrier in front of the step loop)
+            for (int step = 0; step < nsteps; ++step) {
+                __syncthreads();                                     // 1: kernel tile complete
+                __syncthreads();                                     // 4: A2bar tile complete, K tile still intact
+                double kT[XCB][4];
+#pragma unroll
+                for (int cq = 0; cq < XCB; ++cq)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kT[cq][s] = Kt[(16 * (NCB + cq) + nl) * PD + 4 * s + g];
+#pragma unroll
+                for (int rb = 0; rb < NBLK; ++rb) {
+                    double abT[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) abT[s] = A2t[(16 * rb + nl) * PD + 4 * s + g];
+#pragma unroll
+                    for (int cq = 0; cq < XCB; ++cq)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) xacc[rb][cq] = CBF_MFMA(abT[s], kT[cq][s], xacc[rb][cq]);
+                }
+                __syncthreads();                                     // 5
+                __syncthreads();                                     // 6
+            }
+            double* slab = a.gpart + wg_linear * a.slab;
+#pragma unroll
+            for (int rb = 0; rb < NBLK; ++rb)
+#pragma unroll
+                for (int cq = 0; cq < XCB; ++cq)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[SL::gB + (rb * NBLK + NCB + cq) * 256 + r * 64 + l] = xacc[rb][cq][r];
+            return;
+        }
+    }
     CBF_STAMP_DECL;
     double hcur[QPW];
     if (nsteps > 0) {
@@ -796,7 +847,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
                             xp[jb] = CBF_MFMA(ZTp[(jb * 4 + r) * 64], ebar[i][r], xp[jb]);   // rows j, k = m of this block
                 }
             }
-            if constexpr (!PALIAS) {
+            if constexpr (!PALIAS && !XW) {
 #pragma unroll
                 for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
@@ -808,7 +859,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
         for (int i = 0; i < RB; ++i) {
             if (ok[i]) {
                 double ebT[4];
-                double* ownk = Kt + 16 * rbs[i] * PD;   // the K tile is dead after phase E: reuse own rows for Ebar^T
+                // the K tile is dead after phase E: reuse own rows for Ebar^T -- unless the extra wave is still reading
+                // it: then this wave's (not yet written) slot of the partial tiles is the scratch
+                double* ownk = XW ? (part + w * PSL) : (Kt + 16 * rbs[i] * PD);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ownk[(g + 4 * r) * PD + nl] = ebar[i][r];
                 __builtin_amdgcn_wave_barrier();
@@ -827,6 +880,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev_kernel(RevArg
             }
         }
         CBF_STAMP_MARK(8);
+        if constexpr (XW) {
+            __builtin_amdgcn_wave_barrier();     // the transposes above went through this slot
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
+        }
         if constexpr (PALIAS) {
             __syncthreads();                 // every wave is done with its rows of the K tile (Ebar, the transposes)
 #pragma unroll

@@ -38,7 +38,7 @@ int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
         auto k = rev_kernel<NBLK, C::RB, DK, true, C::STASH, MODE>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(64 * C::W), lds, st, a);
+        hipLaunchKernelGGL(k, grid, dim3(64 * (C::W + (rev_extra_wave(NBLK, C::STASH) ? 1 : 0))), lds, st, a);
     } else {
         typedef RevLds<NBLK, C::RB, DK, C::STASH> RL;
         static_assert(RL::BASE_PLAIN == G::LDS_BASE, "LDS layout");
@@ -46,7 +46,7 @@ int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
         auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(64 * C::W), lds, st, a);
+        hipLaunchKernelGGL(k, grid, dim3(64 * (C::W + (rev_extra_wave(NBLK, C::STASH) ? 1 : 0))), lds, st, a);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
