@@ -703,6 +703,17 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         CBF_STAMP_MARK0();
         double eps_n, ytil_n[QPW], fm_n[QPW], fv_n[QPW];     // phase D inputs of the next step, consumed after phase G
         if (has_next) epilogue_load(tn, eps_n, ytil_n, fm_n, fv_n);
+        // (Z~)^T operands of the input-adjoint product below: issued here, in flight under the K^-1 A2bar loop (with the
+        // eighth wave the row-block waves have the registers for it; the product was 7 % of a step waiting for L2)
+        constexpr bool ZTPRE = XW && RB == 1;
+        double ztv[ZTPRE ? JB : 1][4];
+        if constexpr (ZTPRE) {
+            const double* ZTp0 = a.rk.ZT + rbs[0] * JB * 256 + l;
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ztv[jb][r] = ZTp0[(jb * 4 + r) * 64];
+        }
         d4 ebar[RB];
         {
             d4 acc[RB][2];
@@ -844,7 +855,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                     for (int jb = 0; jb < JB; ++jb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            xp[jb] = CBF_MFMA(ZTp[(jb * 4 + r) * 64], ebar[i][r], xp[jb]);   // rows j, k = m of this block
+                            xp[jb] = CBF_MFMA(ZTPRE ? ztv[jb][r] : ZTp[(jb * 4 + r) * 64], ebar[i][r], xp[jb]);   // rows j, k = m of this block
                 }
             }
             if constexpr (!PALIAS && !XW) {
