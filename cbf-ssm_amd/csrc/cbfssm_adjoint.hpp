@@ -519,6 +519,17 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
             }
         }
 
+        // mean / variance B operands of phase E: issued here (eight-wave tiles: the registers are there), under phase B
+        constexpr bool MUPRE = XW && RB == 1 && MODE == MODE_FWD;   // (measured: 4.47 -> 4.32 ms forward-pass adjoint, 5.53 -> 5.63 backward runs)
+        double mBv[MUPRE ? 4 : 1], sBv[MUPRE ? 4 : 1];
+        if constexpr (MUPRE) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                mBv[s] = a.rk.muB[rbs[0] * 256 + s * 64 + l];
+                sBv[s] = a.rk.s2B[rbs[0] * 256 + s * 64 + l];
+            }
+        }
+
         // ---- B: kernel tile (rows of this wave)
         double bx[DK], xx = 0.0;
 #pragma unroll
@@ -643,8 +654,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    T1 = CBF_MFMA(mBp[s * 64], fmB[s], T1);
-                    T2 = CBF_MFMA(sBp[s * 64], fvB[s], T2);
+                    T1 = CBF_MFMA(MUPRE ? mBv[s] : mBp[s * 64], fmB[s], T1);
+                    T2 = CBF_MFMA(MUPRE ? sBv[s] : sBp[s * 64], fvB[s], T2);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a2bar[i][r] = T1[r] + 2.0 * a2[i][r] * T2[r] - kreg[i][r] * fvsum;
