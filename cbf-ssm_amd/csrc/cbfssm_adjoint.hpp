@@ -111,13 +111,14 @@ struct RevLds {
 // BLDS: the K^-1 A-operand image lives in LDS for the whole pass (one copy per workgroup, trimmed to the ceil(M/4)
 // k-steps that carry data); otherwise it streams from L2.  RB: 16-row blocks of inducing points per wave.
 // Seven row-block waves load the four SIMDs 2-2-2-1.  The in-register tiles of that height get an EIGHTH wave, which
-// lands next to wave 3 and takes the last rev_xcb() column blocks of the Kinvbar accumulation for ALL row blocks (its
+// lands next to wave 3 and takes the last REV_XCB column blocks of the Kinvbar accumulation for ALL row blocks (its
 // operands, A2bar and K, are complete in the LDS tiles between the barriers that end phases E and F); it has no other
 // role and leaves before the epilogue (a wave that has ended no longer counts at s_barrier).
 // Measured on the C3 kernels (ms, forward-pass / backward-run adjoint; without the wave 5.12 / 5.83):
 //   1 block 5.14 / 5.59, 2 blocks 4.89 / 5.60, 3 blocks 4.81 / 5.72, 4 blocks 5.11 / 6.01 (the extra wave's 112 MFMAs
-//   no longer fit into phase F next to wave 3's own).  The forward-pass adjoint has the longer phase E (14 outputs).
-constexpr int rev_xcb(int mode) { return mode == MODE_FWD ? 3 : 2; }
+//   no longer fit into phase F next to wave 3's own); with the operand loads of phases E and F issued early (below):
+//   2 blocks 4.68 / 5.54, 3 blocks 4.30 / 5.40, 4 blocks 4.66 / -.
+constexpr int REV_XCB = 3;
 constexpr bool rev_extra_wave(int nblk, bool stash) { return nblk == 7 && !stash; }
 
 template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE>
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     constexpr int PD = 17;                              // padded row length of the LDS tiles
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
     constexpr bool XW = rev_extra_wave(NBLK, STASH);
-    constexpr int XCB = XW ? rev_xcb(MODE) : 0;         // column blocks of Kinvbar accumulated by the extra wave
+    constexpr int XCB = XW ? REV_XCB : 0;               // column blocks of Kinvbar accumulated by the extra wave
     constexpr int NCB = STASH ? 1 : NBLK - XCB;         // ... and by the wave that owns the row block
     constexpr bool ALL_OK = (NBLK % RB == 0);           // every wave owns RB real row blocks (no predicate around MFMAs)
     typedef Slab<NBLK, JB, STASH> SL;
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         }
 
         // mean / variance B operands of phase E: issued here (eight-wave tiles: the registers are there), under phase B
-        constexpr bool MUPRE = XW && RB == 1 && MODE == MODE_FWD;   // (measured: 4.47 -> 4.32 ms forward-pass adjoint, 5.53 -> 5.63 backward runs)
+        // (measured: forward-pass adjoint 4.47 -> 4.32 ms; the backward runs do not gain: 5.42 -> 5.45)
+        constexpr bool MUPRE = XW && RB == 1 && MODE == MODE_FWD;
         double mBv[MUPRE ? 4 : 1], sBv[MUPRE ? 4 : 1];
         if constexpr (MUPRE) {
 #pragma unroll
