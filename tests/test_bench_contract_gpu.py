@@ -1,0 +1,41 @@
+"""The driver's bench contract: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the agreed
+keys, including the `roofline` and `cpu_baseline` objects (run on the smallest workload so that it takes seconds)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), capture_output=True, text=True,
+                         timeout=280, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_bench_line_has_the_contract_keys(mode):
+    rec = _run('--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'C1', '--mode', mode)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in rec, k
+    assert rec['n_gpus'] == 1 and rec['steps'] == 3 and rec['warmup'] == 1
+    assert rec['higher_is_better'] is True and rec['scaling'] == 'weak' and rec['vs_baseline'] is None
+    assert rec['dtype'] == 'f64' and rec['data'] == 'synthetic' and 'workload' in rec['config']
+    assert rec['value'] == pytest.approx(1e3 / rec['ms_per_step'], rel=1e-6)
+    roof = rec['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'hbm_kernel'):
+        assert k in roof, k
+    assert roof['bound'] == 'mfma' and roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'])
+    assert roof['hbm_kernel']['bound'] == 'hbm' and roof['hbm_kernel']['achieved'] > 0
+    cpu = rec['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in cpu, k
+    assert cpu['kind'] == 'port' and cpu['value'] > 0 and cpu['cores'] >= 1
