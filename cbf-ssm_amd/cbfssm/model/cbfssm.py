@@ -174,18 +174,25 @@ class CBFSSM(BaseModel):
             ws = eng.last_ws
         else:
             loss, terms, ws = eng.forward(self._opt.views, u, y, noise, condition)
-        if float(terms['info']) != 0.0:
+        # one device-to-host transfer for everything scalar that this run fetches (each .item() is a stream sync)
+        scal_names = [k for k in ('loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b') if k in names]
+        dev0 = dict(dtype=torch.float64, device=self._device)
+        host = torch.stack([torch.as_tensor(v, **dev0).reshape(())
+                            for v in [terms['info'], loss] + [terms[k] for k in scal_names]]).cpu().numpy()
+        info, loss_h = float(host[0]), float(host[1])
+        scal_h = {k: float(host[2 + i]) for i, k in enumerate(scal_names)}
+        if info != 0.0:
             raise InvalidArgumentError('Cholesky decomposition was not successful: leading minor %d of K_mm + 1e-8 I '
-                                       'is not positive definite' % int(float(terms['info'])))
+                                       'is not positive definite' % int(info))
         S = self.config['samples']
         out = []
         for n in names:
             if n == 'train':
                 out.append(None)
             elif n == 'loss':
-                out.append(np.float64(float(loss)))
+                out.append(np.float64(loss_h))
             elif n in ('loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b'):
-                out.append(np.float64(float(terms[n])))
+                out.append(np.float64(scal_h[n]))
             elif n in ('pred_mean', 'pred_var', 'internal_mean', 'internal_var'):
                 out.append(getattr(ws, {'internal_mean': 'int_mean', 'internal_var': 'int_var'}.get(n, n)).cpu().numpy())
             elif n == 'mse':                                                                          # cbfssm.py:270
