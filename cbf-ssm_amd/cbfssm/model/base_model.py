@@ -40,6 +40,7 @@ class BaseModel:
         self._data = None
         self._order = None
         self._cursor = 0
+        self._staged = None
         self._build_graph()
 
     def _build_graph(self):
@@ -55,6 +56,7 @@ class BaseModel:
         self._order = base[shuffle_order(base.size, int(self.config['shuffle']), self._rng)]
         self._data = (data_in, data_out)
         self._cursor = 0
+        self._staged = None                     # (a mini-batch a model staged ahead belongs to the old iterator)
 
     def _next_batch(self):
         if self._data is None or self._cursor >= self._order.size:

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .base_model import BaseModel
-from .session import Fetch, Saver, InvalidArgumentError
+from .session import Fetch, Saver, InvalidArgumentError, OutOfRangeError
 from ..synthetic import softplus_inverse
 
 _FETCHES = ('train', 'loss', 'pred_mean', 'pred_var', 'internal_mean', 'internal_var', 'mse', 'sde',
@@ -119,6 +119,45 @@ class CBFSSM(BaseModel):
 
     _noise_with_backward = True
 
+    # ---- mini-batches: host gather + upload of batch k+1 overlap the device work of batch k
+    _END = object()
+
+    def _stage_batch(self):
+        data_in, data_out = self._next_batch()                      # raises OutOfRangeError at the end of the data
+        if self._dist is not None:
+            from ..hip.dist_utils import shard_range
+            lo, hi = shard_range(data_in.shape[0], self._rank, self._world)
+            if hi <= lo:
+                raise ValueError('mini-batch of %d sequences cannot be sharded over %d ranks'
+                                 % (data_in.shape[0], self._world))
+            data_in, data_out = data_in[lo:hi], data_out[lo:hi]
+        if getattr(self, '_upload', None) is None:
+            self._upload = torch.cuda.Stream(device=self._device)
+        with torch.cuda.stream(self._upload):                       # not behind the kernels of the running step
+            u = torch.tensor(data_in, device=self._device)
+            y = torch.tensor(data_out, device=self._device)
+            ev = torch.cuda.Event()
+            ev.record(self._upload)
+        return u, y, ev
+
+    def _stage_ahead(self):
+        if self._staged is None:
+            try:
+                self._staged = self._stage_batch()
+            except OutOfRangeError:
+                self._staged = self._END
+
+    def _device_batch(self):
+        staged, self._staged = self._staged, None
+        if staged is self._END:
+            raise OutOfRangeError()
+        u, y, ev = staged if staged is not None else self._stage_batch()
+        cur = torch.cuda.current_stream(self._device)
+        cur.wait_event(ev)
+        u.record_stream(cur)
+        y.record_stream(cur)
+        return u, y
+
     def _train_stepper(self):
         """HipTrainStep over this model's engine and optimiser (CBFSSM only: the variants' recognition networks run in
         the tensor library's autograd, outside the captured launches)."""
@@ -150,16 +189,7 @@ class CBFSSM(BaseModel):
         if 'condition' not in feed:
             raise KeyError('feed_dict must set model.condition (cbfssm.py:227)')
         condition = bool(feed['condition'])
-        data_in, data_out = self._next_batch()
-        if self._dist is not None:
-            from ..hip.dist_utils import shard_range
-            lo, hi = shard_range(data_in.shape[0], self._rank, self._world)
-            if hi <= lo:
-                raise ValueError('mini-batch of %d sequences cannot be sharded over %d ranks'
-                                 % (data_in.shape[0], self._world))
-            data_in, data_out = data_in[lo:hi], data_out[lo:hi]
-        u = torch.tensor(data_in, device=self._device)
-        y = torch.tensor(data_out, device=self._device)
+        u, y = self._device_batch()
         B, T = u.shape[0], u.shape[1]
         noise = self._draw_noise(B, T)
         eng = self._engine
@@ -174,6 +204,7 @@ class CBFSSM(BaseModel):
             ws = eng.last_ws
         else:
             loss, terms, ws = eng.forward(self._opt.views, u, y, noise, condition)
+        self._stage_ahead()     # the next mini-batch: gathered and uploaded while the device works on this one
         # one device-to-host transfer for everything scalar that this run fetches (each .item() is a stream sync)
         scal_names = [k for k in ('loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b') if k in names]
         dev0 = dict(dtype=torch.float64, device=self._device)
