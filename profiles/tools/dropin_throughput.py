@@ -1,5 +1,5 @@
 """Throughput of the drop-in surface itself (reference run/template.py:50-64 flow, Trainer.train) on a C3-shaped
-synthetic dataset: what a user of `cbfssm.model.CBFSSM` + `cbfssm.training.Trainer` gets per train step, next to the
+(or, with an argument, C1-/C2-shaped) synthetic dataset: what a user of `cbfssm.model.CBFSSM` + `cbfssm.training.Trainer` gets per train step, next to the
 `bench.py` number for the bare engine."""
 import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,13 +10,12 @@ from cbfssm.datasets import make_synthetic_ds
 from cbfssm.training import Trainer
 from cbfssm.model import CBFSSM
 
-B, T, nb = 256, 250, 12
-ds_sel = make_synthetic_ds(dim_u=7, dim_y=7, n_train=T * B * nb, n_test=T * B, seed=1)
-dim_x = 14
-cfg = {'ds': ds_sel, 'batch_size': B, 'shuffle': 10000, 'seed': 5, 'dim_x': dim_x, 'ind_pnt_num': 100, 'samples': 20,
-       'learning_rate': 0.05, 'loss_factors': np.asarray([6., 0.]), 'k_factor': 50., 'recog_len': 16,
-       'zeta_pos': 2., 'zeta_mean': 0.05 ** 2, 'zeta_var': 0.01 ** 2, 'var_x': np.asarray([0.002 ** 2] * dim_x),
-       'var_y': np.asarray([0.05 ** 2] * dim_x), 'gp_var': 0.5 ** 2, 'gp_len': 1.}
+from cbfssm import synthetic as syn
+w = syn.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'C3']           # C3 by default; C1 / C2: the launch-bound shapes
+B, T, nb = w.B, w.T, 12
+ds_sel = make_synthetic_ds(dim_u=w.dim_u, dim_y=w.dim_y, n_train=T * B * nb, n_test=T * B, seed=1)
+cfg = dict(w.model_config())
+cfg.update({'ds': ds_sel, 'batch_size': B, 'shuffle': 10000, 'seed': 5})
 ds = ds_sel(T, T)
 model = CBFSSM(cfg)
 with tempfile.TemporaryDirectory() as d:
