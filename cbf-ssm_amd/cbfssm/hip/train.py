@@ -180,7 +180,7 @@ class HipElboGrad:
             terms = {'loglik': red[0], 'kl_x': red[1], 'entropy': red[2], 'kl_z_f': out[3], 'kl_z_b': out[4],
                      'info': out[7]}
         else:
-            loss = out[6]
+            loss = out[6].clone()       # (the terms below stay views into the workspace: the next evaluation overwrites them)
             terms = {'loglik': out[0], 'kl_x': out[1], 'entropy': out[2], 'kl_z_f': out[3], 'kl_z_b': out[4],
                      'info': out[7]}
         self.last_ws = ws
