@@ -1,8 +1,10 @@
-"""Multi-run RMSE summary (cbfssm/outputs/output_summary.py:7-31): copies the driving script, writes summary.txt."""
+"""`OutputSummary(out_dir)`: collects the final RMSE of several runs (`add_outputs(outputs)`) and writes
+`summary.txt` with the per-run values, their mean and standard deviation; the driving script is copied next to it as
+`main.py` (interface of the reference's cbfssm/outputs/output_summary.py:7-31)."""
 import os
+import shutil
 import sys
 import numpy as np
-from shutil import copyfile
 
 
 class OutputSummary:
@@ -10,22 +12,22 @@ class OutputSummary:
     def __init__(self, out_dir):
         self.out_dir = out_dir
         self.rmse_all = []
-        os.makedirs(self.out_dir, exist_ok=True)
-        src = os.path.abspath(sys.argv[0]) if sys.argv and sys.argv[0] else None
-        if src and os.path.isfile(src):
-            copyfile(src, self.out_dir + '/main.py')
+        os.makedirs(out_dir, exist_ok=True)
+        script = sys.argv[0] if sys.argv else ''
+        if script and os.path.isfile(script):
+            shutil.copyfile(os.path.abspath(script), os.path.join(out_dir, 'main.py'))
 
     def add_outputs(self, outputs):
         self.rmse_all.append(outputs.get_last_rmse())
 
     def write_summary(self):
-        if self.rmse_all and self.rmse_all[0] is not None:
-            rmse_all = np.asarray(self.rmse_all, dtype=np.float64)
-            with open(self.out_dir + '/summary.txt', 'w') as f:
-                f.write("RMSE\n====\n\nRuns:\n")
-                for val in rmse_all:
-                    f.write("  %f\n" % val)
-                f.write("Mean: %f\n" % np.mean(rmse_all))
-                f.write("Std:  %f\n" % np.std(rmse_all))
-        else:
+        runs = [r for r in self.rmse_all]
+        if not runs or runs[0] is None:
             print("RMSE summary skipped")
+            return
+        values = np.asarray(runs, dtype=np.float64)
+        lines = ['RMSE', '====', '', 'Runs:']
+        lines += ['  %f' % v for v in values]
+        lines += ['Mean: %f' % values.mean(), 'Std:  %f' % values.std()]
+        with open(os.path.join(self.out_dir, 'summary.txt'), 'w') as fh:
+            fh.write('\n'.join(lines) + '\n')

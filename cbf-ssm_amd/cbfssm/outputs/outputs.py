@@ -1,38 +1,55 @@
-"""Evaluation outputs with the reference's interface and files (cbfssm/outputs/outputs.py:11-164): restore best.ckpt,
-300-step open-loop prediction (condition=False) of the first train/test experiment -> predict_*.mat (+ .pdf when
-matplotlib is importable), per-experiment test RMSE on denormalised outputs -> mse.txt, var_dump.txt."""
-import math
+"""`Outputs(out_dir)`: evaluation artefacts of a trained model, with the method names and files of the reference's
+cbfssm/outputs/outputs.py:11-164 --
+
+    best.ckpt restored, then
+    training_loss.pdf          epoch losses of the attached Trainer (needs matplotlib)
+    predict_{train,test}.mat   free-running prediction (condition=False) of the first experiment, at most 300 steps:
+                               denormalised mean / std / ground truth (+ .pdf with the 1.96 sigma band)
+    mse.txt                    MSE and RMSE of the denormalised free-running prediction, averaged over test experiments
+    var_dump.txt               every entry of model.var_dict
+
+The prediction and RMSE run through `model.pred_mean` / `model.pred_var` with B = 1, i.e. the persistent HIP kernels.
+"""
 import os
 import numpy as np
-import scipy.io
+from scipy.io import savemat
 
 from ..model.session import Session
 
-try:
+try:                                        # figures are optional: the numbers do not depend on matplotlib
     import matplotlib
     matplotlib.use('Agg')
-    import matplotlib.pyplot as plt
-except Exception:            # pragma: no cover
+    from matplotlib import pyplot as plt
+except Exception:                           # pragma: no cover
     plt = None
+
+_BAND_COLOUR = (1.0, 178.0 / 255.0, 110.0 / 255.0)
+
+
+def _rows_as_text(value):
+    """var_dump.txt layout: vectors on one line, matrices one line per row, '% .4e' per entry."""
+    fmt = lambda seq: ''.join('  % .4e' % v for v in seq)
+    if value.ndim == 1:
+        return fmt(value)
+    if value.ndim == 2:
+        return ''.join(fmt(row) + '\n' for row in value)
+    return ''
 
 
 class Outputs:
 
     def __init__(self, out_dir):
+        os.makedirs(out_dir, exist_ok=True)
         self.out_dir = out_dir
-        self.ds = None
-        self.model = None
-        self.model_path = None
-        self.trainer = None
+        self.ds = self.model = self.model_path = self.trainer = None
         self.last_rmse = None
-        os.makedirs(self.out_dir, exist_ok=True)
 
+    # ---- wiring (run/template.py:58-64)
     def set_ds(self, ds):
         self.ds = ds
 
     def set_model(self, model, model_dir):
-        self.model = model
-        self.model_path = model_dir + '/best.ckpt'
+        self.model, self.model_path = model, model_dir + '/best.ckpt'
 
     def set_trainer(self, trainer):
         self.trainer = trainer
@@ -40,89 +57,88 @@ class Outputs:
     def get_last_rmse(self):
         return self.last_rmse
 
+    def _path(self, name):
+        return self.out_dir + '/' + name
+
     def create_all(self):
-        assert self.model is not None
-        assert self.ds is not None
-        with self.model.graph.as_default():
-            with Session() as sess:
-                self.model.saver.restore(sess, self.model_path)
-                print("Generating outputs...")
-                self._create_all(sess)
+        if self.model is None or self.ds is None:
+            raise AssertionError('set_model() and set_ds() come first')
+        with self.model.graph.as_default(), Session() as sess:
+            self.model.saver.restore(sess, self.model_path)
+            print("Generating outputs...")
+            self._create_all(sess)
 
     def _create_all(self, sess):
-        self.training_stats()
-        self.prediction(sess)
-        self.test_mse(sess)
-        self.var_dump(sess)
+        for step in (lambda: self.training_stats(), lambda: self.prediction(sess), lambda: self.test_mse(sess),
+                     lambda: self.var_dump(sess)):
+            step()
 
+    # ---- training curve
     def training_stats(self):
-        if self.trainer is not None and plt is not None:
-            print("  training stats")
-            plt.figure(1)
-            plt.plot(self.trainer.train_all, label='train')
-            plt.plot(self.trainer.test_all, label='test')
-            plt.legend()
-            plt.savefig(self.out_dir + '/training_loss.pdf')
-            plt.close(1)
+        if self.trainer is None or plt is None:
+            return
+        print("  training stats")
+        fig = plt.figure(1)
+        for series, label in ((self.trainer.train_all, 'train'), (self.trainer.test_all, 'test')):
+            plt.plot(series, label=label)
+        plt.legend()
+        fig.savefig(self._path('training_loss.pdf'))
+        plt.close(fig)
 
-    def _predict_one(self, sess, data_in, data_out, tag, predict_size):
-        model, ds = self.model, self.ds
-        model.load_ds(sess, data_in[0:1, :predict_size, :], data_out[0:1, :predict_size, :])
-        pred, var = sess.run((model.pred_mean, model.pred_var), feed_dict={model.condition: False})
-        pred = ds.denormalize(pred, 'out')[0, :, :]
-        gt = ds.denormalize(data_out[0:1, :predict_size, :], 'out')[0, :, :]
-        std = ds.denormalize(np.sqrt(var), 'out', shift=False)[0, :, :]
-        if plt is not None:
-            lower, upper = pred[:, 0] - 1.96 * std[:, 0], pred[:, 0] + 1.96 * std[:, 0]
-            plt.figure(1, figsize=(6, 4))
-            plt.plot(gt[:, 0], label='ground truth')
-            plt.plot(pred[:, 0], label='prediction')
-            plt.fill_between(range(predict_size), lower, upper, color=(1.0, 178. / 255., 110. / 255.))
-            plt.legend(loc=2)
-            plt.grid(True)
-            plt.xlabel("time (steps)")
-            plt.xlim([0, predict_size])
-            plt.savefig(self.out_dir + '/predict_%s.pdf' % tag, bbox_inches='tight')
-            plt.close(1)
-        scipy.io.savemat(self.out_dir + '/predict_%s.mat' % tag, {'mean': pred, 'std': std, 'gt': gt})
+    # ---- free-running prediction of one experiment
+    def _free_run(self, sess, data_in, data_out, fetches):
+        m = self.model
+        m.load_ds(sess, data_in, data_out)
+        return sess.run(fetches, feed_dict={m.condition: False})
+
+    def _predict_one(self, sess, data_in, data_out, tag, steps):
+        ds = self.ds
+        first_in, first_out = data_in[:1, :steps], data_out[:1, :steps]
+        mean_n, var_n = self._free_run(sess, first_in, first_out, (self.model.pred_mean, self.model.pred_var))
+        mean = ds.denormalize(mean_n, 'out')[0]
+        std = ds.denormalize(np.sqrt(var_n), 'out', shift=False)[0]
+        truth = ds.denormalize(first_out, 'out')[0]
+        savemat(self._path('predict_%s.mat' % tag), {'mean': mean, 'std': std, 'gt': truth})
+        if plt is None:
+            return
+        fig = plt.figure(1, figsize=(6, 4))
+        plt.plot(truth[:, 0], label='ground truth')
+        plt.plot(mean[:, 0], label='prediction')
+        half = 1.96 * std[:, 0]
+        plt.fill_between(np.arange(steps), mean[:, 0] - half, mean[:, 0] + half, color=_BAND_COLOUR)
+        plt.legend(loc=2)
+        plt.grid(True)
+        plt.xlabel("time (steps)")
+        plt.xlim([0, steps])
+        fig.savefig(self._path('predict_%s.pdf' % tag), bbox_inches='tight')
+        plt.close(fig)
 
     def prediction(self, sess, predict_size=300):
         print("  prediction")
-        ds = self.ds
-        predict_size = min(ds.train_in.shape[1], predict_size)
-        self._predict_one(sess, ds.train_in, ds.train_out, 'train', predict_size)
-        self._predict_one(sess, ds.test_in, ds.test_out, 'test', min(ds.test_in.shape[1], predict_size))
+        for tag in ('train', 'test'):
+            data_in, data_out = getattr(self.ds, tag + '_in'), getattr(self.ds, tag + '_out')
+            self._predict_one(sess, data_in, data_out, tag, min(predict_size, data_in.shape[1]))
 
+    # ---- test error
     def test_mse(self, sess):
         print("  test mse")
-        model, ds = self.model, self.ds
-        mse_all = []
-        for i in range(ds.test_in.shape[0]):
-            model.load_ds(sess, ds.test_in[i:i + 1, :, :], ds.test_out[i:i + 1, :, :])
-            pred = model.run(sess, model.pred_mean, {model.condition: False})[0]
-            pred = ds.denormalize(pred, 'out')[0]
-            gt = ds.denormalize(ds.test_out[i:i + 1, :, :], 'out')[0]
-            mse_all.append(np.mean(np.square(gt - pred)))        # sklearn mean_squared_error, uniform average
-        mse_all = float(np.mean(np.asarray(mse_all)))
-        rmse_all = math.sqrt(mse_all)
-        with open(self.out_dir + '/mse.txt', 'w') as f:
-            f.write("MSE:  %f\n" % mse_all)
-            f.write("RMSE: %f\n" % rmse_all)
-        self.last_rmse = rmse_all
+        m, ds = self.model, self.ds
+        per_experiment = []
+        for k in range(ds.test_in.shape[0]):
+            m.load_ds(sess, ds.test_in[k:k + 1], ds.test_out[k:k + 1])
+            pred = m.run(sess, m.pred_mean, {m.condition: False})[0]
+            err = ds.denormalize(ds.test_out[k:k + 1], 'out')[0] - ds.denormalize(pred, 'out')[0]
+            per_experiment.append(np.mean(err * err))            # mean over time and output dims, uniform weights
+        mse = float(np.mean(per_experiment))
+        self.last_rmse = float(np.sqrt(mse))
+        with open(self._path('mse.txt'), 'w') as fh:
+            fh.write("MSE:  %f\nRMSE: %f\n" % (mse, self.last_rmse))
 
+    # ---- parameters
     def var_dump(self, sess):
         print("  var dump")
-        model = self.model
-        with open(self.out_dir + '/var_dump.txt', 'w') as f:
-            for name, variable in model.var_dict.items():
-                value = np.asarray(sess.run(variable, feed_dict={model.condition: False}))
-                f.write(name + ":\n")
-                if value.ndim == 1:
-                    for val in value:
-                        f.write("  % .4e" % val)
-                elif value.ndim == 2:
-                    for row in value:
-                        for val in row:
-                            f.write("  % .4e" % val)
-                        f.write('\n')
-                f.write("\n\n")
+        m = self.model
+        with open(self._path('var_dump.txt'), 'w') as fh:
+            for name, fetch in m.var_dict.items():
+                value = np.asarray(sess.run(fetch, feed_dict={m.condition: False}))
+                fh.write('%s:\n%s\n\n' % (name, _rows_as_text(value)))
