@@ -113,9 +113,12 @@ __global__ void contract_reduce_kernel(const double* part, int64_t n, int nsplit
 
 static int contract_split(int64_t nslots)
 {
-    // ~256 slices (two row groups => ~512 workgroups), at least 8 slots each
+    // ~256 slices (two row groups => ~512 workgroups), at least 8 slots each.  A multiple of 8: the grid is (slice, row
+    // group) and workgroups go to the eight XCDs round-robin by linear id, so the row-group workgroups of one slice
+    // (ids x, x + nsplit, ...) land on the SAME XCD and the second one finds the slice's B images in that XCD's L2.
     int64_t n = nslots / 8;
     if (n > 256) n = 256;
+    if (n >= 8) n &= ~int64_t(7);
     if (n < 1) n = 1;
     return int(n);
 }
