@@ -70,6 +70,23 @@ struct RevArgs {
     const double* fmv;     // (fmean, fvar) of every step as saved by the forward evaluation (PassArgs::fmv layout)
 };
 
+// Reciprocal and reciprocal square root for the epilogue-adjoint chain (phase D sits on the serial path of a step): the
+// hardware seed and two Newton steps, 1-2 ulp, about half the dependent instructions of the IEEE division / sqrt
+// sequences.  Arguments are variances: positive, finite, far from the subnormal range.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return fma(y, fma(-hx * y, y, 0.5), y);
+}
+
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
 template <int NBLK, int JB, bool STASH>
 struct Slab {
@@ -384,17 +401,17 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                             const double kf1 = a.k_factor - 1.0;
                             const double vyt = vy[qi] + kf1 * fvar;
                             const double s = vyt + fvar;
-                            const double rs = 1.0 / s;
+                            const double rs = fast_rcp(s);
                             const double k = fvar * rs;
                             const double ydiff = ytil[qi] - fmean;
                             const double mu = fmean + k * ydiff;
                             const double omk = 1.0 - k;
                             const double sig = omk * omk * fvar + k * k * vyt;
-                            const double rf = 1.0 / fvar, rsig = 1.0 / sig;
+                            const double rf = fast_rcp(fvar), rsig = fast_rcp(sig);
                             const double dm = mu - fmean;
                             // x' = mu + eps sqrt(sig);  kl = .5[log fvar - log sig + (sig + dm^2)/fvar - 1]
                             const double gmu = gout + a.cL * dm * rf;
-                            const double gsg = gout * eps_t * 0.5 * sqrt(rsig) + a.cL * 0.5 * (rf - rsig);
+                            const double gsg = gout * eps_t * 0.5 * fast_rsqrt(sig) + a.cL * 0.5 * (rf - rsig);
                             gfm = -a.cL * dm * rf;
                             gfv = a.cL * 0.5 * (rf - (sig + dm * dm) * rf * rf);
                             // mu = fmean + k (ytil - fmean)
@@ -416,7 +433,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                         } else {
                             // x' = fmean + eps sqrt(fvar), no KL term                           (cbfssm.py:224,234)
                             gfm = gout;
-                            gfv = gout * eps_t * 0.5 / sqrt(fvar);
+                            gfv = gout * eps_t * 0.5 * fast_rsqrt(fvar);
                             if (d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
                         }
                     } else {
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                         const bool write = (run == 0) ? (tm < R) : (tm >= R);
                         const double gtot = gout + (write ? gy2in[qi] : 0.0);
                         gfm = gtot;
-                        gfv = gtot * eps_t * 0.5 / sqrt(fvar) - (write ? a.cE * 0.5 / fvar : 0.0);
+                        gfv = gtot * eps_t * 0.5 * fast_rsqrt(fvar) - (write ? a.cE * 0.5 * fast_rcp(fvar) : 0.0);
                     }
                     gvx[qi] += gfv;
                     gsig += gfv;
