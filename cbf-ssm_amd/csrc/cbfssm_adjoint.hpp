@@ -70,23 +70,6 @@ struct RevArgs {
     const double* fmv;     // (fmean, fvar) of every step as saved by the forward evaluation (PassArgs::fmv layout)
 };
 
-// Reciprocal and reciprocal square root for the epilogue-adjoint chain (phase D sits on the serial path of a step): the
-// hardware seed and two Newton steps, 1-2 ulp, about half the dependent instructions of the IEEE division / sqrt
-// sequences.  Arguments are variances: positive, finite, far from the subnormal range.
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(r, fma(-x, r, 1.0), r);
-    return fma(r, fma(-x, r, 1.0), r);
-}
-__device__ __forceinline__ double fast_rsqrt(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = fma(y, fma(-hx * y, y, 0.5), y);
-    return fma(y, fma(-hx * y, y, 0.5), y);
-}
-
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
 template <int NBLK, int JB, bool STASH>
 struct Slab {

@@ -24,6 +24,24 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 #define CBF_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+// Reciprocal and reciprocal square root for the step epilogues and their adjoints (they sit on the serial path of a
+// time step): the
+// hardware seed and two Newton steps, 1-2 ulp, about half the dependent instructions of the IEEE division / sqrt
+// sequences.  Arguments are variances: positive, finite, far from the subnormal range.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return fma(y, fma(-hx * y, y, 0.5), y);
+}
+
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 
 // Diagnostic build only (-DCBF_REV_STAMPS): per-phase cycle shares of the adjoint step, compute vs barrier wait, summed
@@ -846,24 +864,25 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                     if (MODE == MODE_FWD) {
                         const double vyt = vy[qi] + (a.k_factor - 1.0) * fvar;         // cbfssm.py:212-214
                         const double s = vyt + fvar;                                   // :216
-                        const double kk = fvar * (1.0 / s);                            // :217
+                        const double kk = fvar * fast_rcp(s);                          // :217
                         const double ydiff = ytil[qi] - fmean;                         // :215
                         const double mu = fmean + kk * ydiff;                          // :218
                         const double omk = 1.0 - kk;
                         const double sig = omk * omk * fvar + kk * kk * vyt;           // :219-220
                         // half: the hidden dims (d >= dim_y) get no Kalman update: k = 0, mu = fmean, sig = fvar, KL = 0
                         const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);     // :227
-                        outv = do_cond ? (mu + eps_t[qi] * sqrt(sig)) : (fmean + eps_t[qi] * sqrt(fvar));   // :221-229
+                        outv = do_cond ? (mu + eps_t[qi] * (sig * fast_rsqrt(sig)))                         // :221-229
+                                       : (fmean + eps_t[qi] * (fvar * fast_rsqrt(fvar)));
                         if (do_cond && cval[qi]) {
                             // kl_reg = log fvar - log sig + (sig + (mu - fmean)^2)/fvar - 1        (:232)
-                            const double rf = 1.0 / fvar;
+                            const double rf = fast_rcp(fvar);
                             const double dm = mu - fmean;
                             lin[qi] += (sig + dm * dm) * rf - 1.0;
                             lp[qi].mul(sig * rf);
                         }
                         if (cval[qi]) a.x_out[(int64_t(t + 1) * N + c) * a.dim_x + d] = outv;       // :229
                     } else {
-                        outv = fmean + eps_t[qi] * sqrt(fvar);                         // cbfssm.py:150
+                        outv = fmean + eps_t[qi] * (fvar * fast_rsqrt(fvar));          // cbfssm.py:150
                         const bool write = (run == 0) ? (tmod < R) : (tmod >= R);             // :125,128
                         if (cval[qi]) {
                             if (write) {
@@ -1099,22 +1118,22 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
                     if (MODE == MODE_FWD) {
                         const double vyt = vy[c][qi] + (a.k_factor - 1.0) * fvar;
                         const double sm = vyt + fvar;
-                        const double kk = fvar * (1.0 / sm);
+                        const double kk = fvar * fast_rcp(sm);
                         const double ydiff = ytil - fmean;
                         const double mu = fmean + kk * ydiff;
                         const double omk = 1.0 - kk;
                         const double sig = omk * omk * fvar + kk * kk * vyt;
                         const bool do_cond = a.condition || (t < R - 1);
-                        outv = do_cond ? (mu + eps_t * sqrt(sig)) : (fmean + eps_t * sqrt(fvar));
+                        outv = do_cond ? (mu + eps_t * (sig * fast_rsqrt(sig))) : (fmean + eps_t * (fvar * fast_rsqrt(fvar)));
                         if (do_cond && cval[c]) {
-                            const double rf = 1.0 / fvar;
+                            const double rf = fast_rcp(fvar);
                             const double dm = mu - fmean;
                             lin[c][qi] += (sig + dm * dm) * rf - 1.0;
                             lp[c][qi].mul(sig * rf);
                         }
                         if (cval[c]) a.x_out[(int64_t(t + 1) * N + cch) * a.dim_x + d] = outv;
                     } else {
-                        outv = fmean + eps_t * sqrt(fvar);
+                        outv = fmean + eps_t * (fvar * fast_rsqrt(fvar));
                         const bool write = (run == 0) ? (tmod < R) : (tmod >= R);
                         if (cval[c]) {
                             if (write) {
