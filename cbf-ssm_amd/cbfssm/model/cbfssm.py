@@ -133,9 +133,22 @@ class CBFSSM(BaseModel):
             data_in, data_out = data_in[lo:hi], data_out[lo:hi]
         if getattr(self, '_upload', None) is None:
             self._upload = torch.cuda.Stream(device=self._device)
+        # through page-locked staging buffers (two per shape, alternating: the copy of batch k+1 is asynchronous while
+        # batch k's buffer may still be in flight); a pageable upload of fresh numpy pages every step is at the mercy
+        # of the host's paging state (observed: sporadically 20 ms instead of 0.7 ms for 7 MB)
+        pins = getattr(self, '_pins', None)
+        if pins is None:
+            pins = self._pins = {}
+        key = (data_in.shape, data_out.shape)
+        if key not in pins:
+            pins[key] = [[torch.empty(s, dtype=torch.float64).pin_memory() for s in key] for _ in range(2)] + [0]
+        slot = pins[key][pins[key][2]]
+        pins[key][2] ^= 1
+        slot[0].numpy()[...] = data_in
+        slot[1].numpy()[...] = data_out
         with torch.cuda.stream(self._upload):                       # not behind the kernels of the running step
-            u = torch.tensor(data_in, device=self._device)
-            y = torch.tensor(data_out, device=self._device)
+            u = slot[0].to(self._device, non_blocking=True)
+            y = slot[1].to(self._device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._upload)
         return u, y, ev
