@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 
     // ---- phase D/G lane state.  Phase D lanes: (d = 4q+g, chain nl), q = w + qi*W < 4.
     constexpr int QPW = TT::QPW;
-    double vx[QPW], vy[QPW], il[QPW];
+    double vx[QPW], vy[QPW], il[QPW], ivy[QPW];
     double gcar[QPW];          // adjoint of the chain state arriving from the previously processed step
     double gdir[QPW];          // direct (residual) path adjoint of this step's input state
     double gvx[QPW], gvy[QPW];
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         vx[qi] = a.var_x[dc];
         vy[qi] = (MODE == MODE_FWD) ? a.var_y[(a.half && dc >= a.dim_y) ? 0 : dc] : 0.0;
         il[qi] = a.pk.invl[dc];
+        ivy[qi] = (MODE == MODE_FWD) ? 1.0 / vy[qi] : 0.0;
         gcar[qi] = 0.0; gdir[qi] = 0.0; gvx[qi] = 0.0; gvy[qi] = 0.0;
     }
     // Phase G lanes: input row j = 4*gi + g, gi = w + k*W < NG
@@ -716,6 +717,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         CBF_STAMP_MARK0();
         double eps_n, ytil_n[QPW], fm_n[QPW], fv_n[QPW];     // phase D inputs of the next step, consumed after phase G
         if (has_next) epilogue_load(tn, eps_n, ytil_n, fm_n, fv_n);
+        // y_t of this lane for the log-likelihood term of phase G: issued here, not on the carry chain
+        double ycur[QPW];
+        if (MODE == MODE_FWD) {
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) {
+                const int d = 4 * (w + qi * W) + g;
+                ycur[qi] = (act[qi] && d < a.dim_y) ? a.y[(int64_t(bq) * T + t) * a.dim_y + d] : 0.0;
+            }
+        }
         // (Z~)^T operands of the input-adjoint product below: issued here, in flight under the K^-1 A2bar loop (with the
         // eighth wave the row-block waves have the registers for it; the product was 7 % of a step waiting for L2)
         constexpr bool ZTPRE = XW && RB == 1;
@@ -957,8 +967,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                                 const int d = 4 * q + g;
                                 if (act[qi] && cvalid) {
                                     if ((t >= 1 || a.half) && d < a.dim_y) {
-                                        const double yv = a.y[(int64_t(bq) * T + t) * a.dim_y + d];
-                                        gin += -a.cL * (yv - hcur[qi]) / vy[qi];
+                                        gin += -a.cL * (ycur[qi] - hcur[qi]) * ivy[qi];
                                     }
                                     if (t == 0) {
                                         if (a.half) a.gx0[int64_t(c) * a.dim_x + d] = gin;       // x_0 = recognition model
