@@ -8,7 +8,9 @@ transforms, K_mm/Cholesky/K^-1 + operand packing for both GPs, both backward (re
 reference training/trainer.py:46) and, for mode=train, the adjoint pass + Adam update (trainer.py:40).
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank holds the same per-GPU workload
-(weak scaling: the global batch is N x B sequences) and the ranks exchange one all-reduce per step.
+(weak scaling: the global batch is N x B sequences) and the ranks exchange ONE all-reduce per step.  The default
+workload is C3 (Sarcos M=100, the config the metric is quoted on) at N=1 and C4 (Sarcos M=200, 256 sequences per GPU =
+BASELINE.json's 8-GPU config) at N>1; --workload overrides.
 """
 import argparse
 import json
@@ -28,41 +30,75 @@ F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (spec); csrc/probe/mfma_f64_p
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(w, mode='eval', seconds_budget=25.0, threads=16):
-    """The op-for-op PyTorch-CPU float64 restatement (oracle/cbfssm_torch_ref.py) on the host cores, on a bounded
-    sample: the same workload with T truncated (cost is exactly linear in the number of GP calls 3T-1).  mode=train
-    times loss + reverse-mode gradient (what TF's minimize() executes), mode=eval the loss only."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(w, mode='eval', full=False):
+    """The op-for-op PyTorch-CPU float64 restatement (oracle/cbfssm_torch_ref.py) of the reference's TF-1.8 graph, timed
+    on this box's host cores (BASELINE.md section 2 / SURVEY.md section 8d) on a BOUNDED sample of the same workload:
+    every size as configured (recog_len too), only T cut to 64 steps (191 of 3T-1 GP calls; the op sequence is exactly
+    linear in the number of GP calls, which the T = 8 timing next to it checks), scaled to the full T.  Two thread
+    settings: the reference's own session config (5 intra-op / 10 inter-op threads, training/trainer.py:22-26) and all
+    cores.  `full=True` (bench.py --cpu-baseline full) times the full-T step once instead (about 25-60 s per step and
+    30 GB of autograd state at C3).  mode=train times loss + reverse-mode gradient (what minimize() executes)."""
     from cbfssm import synthetic as syn
     from oracle import cbfssm_torch_ref as tref
     import dataclasses
-    torch.set_num_threads(threads)
-    T_s = min(w.T, 8)
-    ws = dataclasses.replace(w, T=T_s, recog_len=min(w.recog_len, 2))
-    cfg = ws.model_config()
-    p = {k: torch.tensor(v) for k, v in syn.make_params(ws).items()}
-    u, y = (torch.tensor(a) for a in syn.make_inputs(ws))
-    noise = {k: torch.tensor(v) for k, v in syn.make_noise(ws).items()}
-    times = []
-    t_all = time.perf_counter()
-    for i in range(5):
-        t0 = time.perf_counter()
-        if mode == 'train':
-            pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-            tref.elbo_step(cfg, pg, u, y, noise, True)['loss'].backward()
-        else:
-            with torch.no_grad():
-                tref.elbo_step(cfg, p, u, y, noise, True)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > seconds_budget and i >= 1:
-            break
-    t_sample = float(np.median(times[1:] if len(times) > 1 else times))
-    scale = (3 * w.T - 1) / (3 * T_s - 1)
-    t_full = t_sample * scale
-    return {'value': 1.0 / t_full, 'unit': 'steps/s', 'cores': threads, 'kind': 'port',
-            'sample': '%s step of %s with T truncated to %d (%d of %d GP calls), median of %d runs = %.3f s, '
-                      'scaled linearly to T=%d; PyTorch-CPU float64 restatement of the TF-1.8 op sequence%s, %d threads'
-                      % (mode, w.name, T_s, 3 * T_s - 1, 3 * w.T - 1, max(1, len(times) - 1), t_sample, w.T,
-                         ' + reverse-mode autodiff' if mode == 'train' else '', threads)}
+    ncores = os.cpu_count() or 1
+    try:
+        torch.set_num_interop_threads(10)                    # trainer.py:25 (can only be set once per process)
+    except RuntimeError:
+        pass
+
+    def timed(T_s, threads, reps):
+        torch.set_num_threads(threads)
+        ws = dataclasses.replace(w, T=T_s)
+        cfg = ws.model_config()
+        p = {k: torch.tensor(v) for k, v in syn.make_params(ws).items()}
+        u, y = (torch.tensor(a) for a in syn.make_inputs(ws))
+        noise = {k: torch.tensor(v) for k, v in syn.make_noise(ws).items()}
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            if mode == 'train':
+                pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+                tref.elbo_step(cfg, pg, u, y, noise, True)['loss'].backward()
+            else:
+                with torch.no_grad():
+                    tref.elbo_step(cfg, p, u, y, noise, True)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    calls = lambda T: 3 * T - 1
+    T_s = w.T if full else min(w.T, 64)
+    T_0 = min(w.T, 8)
+    t8 = timed(T_0, ncores, 3)                               # warm-up + the linearity check's short sample
+    t8 = float(np.median(t8[1:]))
+    reps = 1 if full else 2                                  # (the first run of a size pays the allocator's first touch)
+    t_all = float(min(timed(T_s, ncores, reps)))
+    t_ref = float(min(timed(T_s, 5, reps)))
+    scale = calls(w.T) / calls(T_s)
+    per_call_ratio = (t_all / calls(T_s)) / (t8 / calls(T_0))
+    best = min(t_all, t_ref) * scale
+    return {'value': 1.0 / best, 'unit': 'steps/s', 'cores': ncores, 'cpu_model': _cpu_model(), 'kind': 'port',
+            'threads': {'all_cores': {'intra_op': ncores, 'seconds_per_step': t_all * scale},
+                        'reference_session_config': {'intra_op': 5, 'inter_op': 10, 'seconds_per_step': t_ref * scale}},
+            'sample_T': T_s, 'sample_gp_calls': calls(T_s), 'full_gp_calls': calls(w.T), 'extrapolated': T_s != w.T,
+            'linearity_T%d_vs_T%d_per_call' % (T_s, T_0): per_call_ratio,
+            'sample': '%s step of %s, every size as configured (M=%d B=%d S=%d recog_len=%d), T = %d of %d (%d of %d GP '
+                      'calls): %.2f s on all %d cores, %.2f s with the reference session config (5 intra-op / 10 '
+                      'inter-op threads)%s; time per GP call at T=%d is %.2fx that at T=%d; PyTorch-CPU float64 '
+                      'restatement of the TF-1.8 op sequence%s; value = the faster of the two settings'
+                      % (mode, w.name, w.M, w.B, w.S, w.recog_len, T_s, w.T, calls(T_s), calls(w.T), t_all, ncores, t_ref,
+                         '' if T_s == w.T else ', scaled linearly to T=%d' % w.T, T_s, per_call_ratio, T_0,
+                         ' + reverse-mode autodiff' if mode == 'train' else '')}
 
 
 def main():
@@ -70,9 +106,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='C3')
+    ap.add_argument('--workload', default=None,
+                    help='C1..C5 (default: C3 on one GPU -- the config the metric is quoted on; C4, the 8-GPU '
+                         'config of BASELINE.json, 256 sequences per GPU, when --gpus > 1)')
     ap.add_argument('--mode', default='auto', choices=['auto', 'eval', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline', default='sample', choices=['sample', 'full'])
     args = ap.parse_args()
 
     from cbfssm import synthetic as syn
@@ -98,6 +137,8 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
+    if args.workload is None:
+        args.workload = 'C3' if args.gpus == 1 else 'C4'
     w = syn.WORKLOADS[args.workload]
     cfg = w.model_config()
     mode = args.mode
@@ -253,14 +294,20 @@ def main():
         name = max(kern, key=lambda k: kern[k][0])
         tk, fl = kern[name]
         ach = fl / tk / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic.json')
-        if os.path.exists(tpath):
-            # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/tools/collect_traffic.sh)
-            tj = json.load(open(tpath))
-            traffic = tj.get('%s:%s' % (args.workload, mode), {}).get(name)     # measured per workload AND mode
+        # HBM bytes per launch of that kernel: NOT measured in this run -- rocprofv3 PMC passes of this same command
+        # (profiles/tools/collect_traffic.sh) are committed per round; the newest file that has the entry is quoted and
+        # named in `traffic_source`
+        traffic, traffic_source = None, None
+        for rnd in ('r02', 'r01'):
+            tpath = os.path.join(ROOT, 'profiles', rnd, 'traffic.json')
+            if os.path.exists(tpath):
+                val = json.load(open(tpath)).get('%s:%s' % (args.workload, mode), {}).get(name)
+                if val is not None:
+                    traffic, traffic_source = val, 'profiles/%s/traffic.json (rocprofv3 --pmc, static)' % rnd
+                    break
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'kernel': name,
+                'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
+                'kernel': name,
                 'kernel_ms': {k: v[0] * 1e3 for k, v in kern.items()},
                 'kernel_tflops': {k: v[1] / v[0] / 1e12 for k, v in kern.items()},
                 'hbm_kernel': {'kernel': 'loglik_moments', 'bound': 'hbm', 'ms': t_ll * 1e3,
@@ -285,7 +332,7 @@ def main():
             'roofline': roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            rec['cpu_baseline'] = cpu_baseline(w, mode)
+            rec['cpu_baseline'] = cpu_baseline(w, mode, full=(args.cpu_baseline == 'full'))
             rec['speedup_vs_cpu_baseline'] = rec['value'] / rec['cpu_baseline']['value']
         else:
             rec['cpu_baseline'] = None

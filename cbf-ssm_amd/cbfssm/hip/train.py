@@ -59,10 +59,11 @@ class StashContract:
     """d loss / d K^-1 += A2bar K^T over the operand images a stash-mode launch left in HBM (cbfssm_stash_contract_f64).
     The result is an MFMA C-layout image [NBLK][NBLK][4][64]; `dense()` gives the (Mp, Mp) matrix."""
 
-    def __init__(self, pack, device):
+    def __init__(self, pack, device, image=None):
         self.pack = pack
         self.n = pack.layout.NBLK * pack.layout.NBLK * 256
-        self.image = torch.zeros(self.n, dtype=torch.float64, device=device)
+        self.image = image if image is not None else torch.zeros(self.n, dtype=torch.float64, device=device)
+        assert self.image.numel() == self.n
         self.work = None
 
     def add(self, sa, sk, cols, stream):
@@ -104,9 +105,13 @@ class HipElboGrad:
         self.slab_f = max(0, int(self.pack_f.layout.rev_slab))
         self.slab_b = max(0, int(self.pack_b.layout.rev_slab))
         self.last_ws = None
-        # flat reduce buffer: [slab_f | slab_b | loglik, kl_x, entropy, gvy_ll[dim_y]]
-        self.nred = self.slab_f + self.slab_b + 3 + self.dim_y
-        self.red = torch.zeros(self.nred, dtype=torch.float64, device=self.device)
+        # flat reduce buffer: [slab_f | slab_b | loglik, kl_x, entropy, gvy_ll[dim_y] | stash mode: the two contracted
+        # d loss / d K^-1 images] -- everything a data-parallel step exchanges, in ONE all-reduce
+        self.ntail = 3 + self.dim_y
+        self.nred = self.slab_f + self.slab_b + self.ntail
+        self.nimg_f = self.pack_f.layout.NBLK ** 2 * 256 if self.stash else 0
+        self.nimg_b = self.pack_b.layout.NBLK ** 2 * 256 if self.stash else 0
+        self.red = torch.zeros(self.nred + self.nimg_f + self.nimg_b, dtype=torch.float64, device=self.device)
         self._ws = {}
         # train-step tail in HIP (positivity transforms, K_mm/K^-1 adjoint + prior KL, chain rule): flat vectors in
         # PARAM_NAMES order.  CBFSSM_TORCH_TAIL=1 keeps the tensor-library restatement below (same numbers, ~170 launches).
@@ -152,8 +157,10 @@ class HipElboGrad:
         c['var_y'] = tf_forward(p['var_y_unc']).contiguous()
         return c
 
-    def forward(self, params, u, y, noise, condition=True):
-        """Loss only (what Trainer's test pass and Outputs fetch): returns (loss 0-d tensor, terms, workspace)."""
+    def forward(self, params, u, y, noise, condition=True, weight=1.0, local=False):
+        """Loss only (what Trainer's test pass and Outputs fetch): returns (loss 0-d tensor, terms, workspace).
+        Data parallel: `weight` scales this rank's data terms in the all-reduce (0 for a stand-in shard on a rank that
+        got no sequence); `local=True` evaluates without the collective (every rank holds the whole batch)."""
         dev = self.device
         cfg = self.config
         u, y = _f64(u, dev), _f64(y, dev)
@@ -170,9 +177,11 @@ class HipElboGrad:
         hid_b, eps_b, eps_f = (_f64(noise[k], dev) for k in ('hid_b', 'eps_b', 'eps_f'))
         self._elbo_forward(prob, ws, c, u, y, hid_b, eps_b, eps_f)
         out = ws.out
-        if self.dist is not None:
+        if self.dist is not None and not local:
             # data terms summed over the ranks' shards, prior KL counted once (cbfssm.py:257-261)
             red = out[0:3].clone()
+            if weight != 1.0:
+                red.mul_(float(weight))
             all_reduce_sum(red, self.dist)
             lf = cfg['loss_factors']
             cL, cE = float(lf[0]) / self.S, float(lf[1]) / self.S
@@ -204,21 +213,23 @@ class HipElboGrad:
             self._ws[key] = ws
         return self._ws[key]
 
-    def loss_and_grads(self, params, u, y, noise, condition=True):
-        """params: dict of unconstrained float64 device tensors.  Returns (loss 0-d tensor, grads dict, terms)."""
+    def loss_and_grads(self, params, u, y, noise, condition=True, weight=1.0, local=False):
+        """params: dict of unconstrained float64 device tensors.  Returns (loss 0-d tensor, grads dict, terms).
+        `weight`, `local`: as in forward()."""
         s = self._grads_local(params, u, y, noise, condition)
-        self._grads_collective(s)
+        if not local:
+            self._grads_collective(s, weight)
         return self._grads_finish(s)
 
     # A train step in three parts, so that a data-parallel step can replay the device work on either side of the
     # collective from HIP graphs (HipTrainStep): everything up to this rank's reduced sums `red`, the all-reduce, the
     # once-per-step tail.
-    def _grads_collective(self, s):
+    def _grads_collective(self, s, weight=1.0):
         if self.dist is not None:
-            all_reduce_sum(self.red, self.dist)     # the one collective of a train step (RCCL over xGMI)
-            if self.stash:
-                all_reduce_sum(s['gB_f'], self.dist)
-                all_reduce_sum(s['gB_b'], self.dist)
+            if weight != 1.0:
+                self.red.mul_(float(weight))
+            all_reduce_sum(self.red, self.dist)     # the ONE collective of a train step (RCCL over xGMI); in stash mode
+                                                    # the contracted K^-1-adjoint images ride in the same buffer
 
     def _grads_local(self, params, u, y, noise, condition=True):
         self._need_adjoint()
@@ -268,7 +279,7 @@ class HipElboGrad:
         else:
             gB_f, gB_b = self._adjoint_stash(prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red)
         # ---- data scalars and the log-likelihood's pull on var_y (cbfssm.py:245-251)
-        tail = red[sf + sb:]
+        tail = red[sf + sb:sf + sb + self.ntail]
         _l.check(lib.cbfssm_data_tail_f64(pb, _ptr(c['var_y']), _ptr(ws.ll_part), _ptr(ws.out), cL, _ptr(tail), st),
                  'cbfssm_data_tail_f64')
         return dict(ws=ws, p=p, c=c, pflat=pflat, gB_f=gB_f, gB_b=gB_b, cL=cL, cE=cE)
@@ -280,7 +291,7 @@ class HipElboGrad:
         ws, p, c, pflat, gB_f, gB_b, cL, cE = (s[k] for k in ('ws', 'p', 'c', 'pflat', 'gB_f', 'gB_b', 'cL', 'cE'))
         red = self.red
         sf, sb = self.slab_f, self.slab_b
-        tail = red[sf + sb:]
+        tail = red[sf + sb:sf + sb + self.ntail]
         loglik, kl_x, entropy = tail[0], tail[1], tail[2]
         kl_z_f, kl_z_b = self.pack_f.scal[_l.SCAL_KLZ], self.pack_b.scal[_l.SCAL_KLZ]
         if self.dist is not None:
@@ -456,7 +467,9 @@ class HipElboGrad:
         red[:sf + sb].zero_()
         tmp_f, tmp_b = torch.zeros(max(sf, 1), **f), torch.zeros(max(sb, 1), **f)
         if getattr(self, '_contract', None) is None:
-            self._contract = (StashContract(self.pack_f, dev), StashContract(self.pack_b, dev))
+            o = self.nred
+            self._contract = (StashContract(self.pack_f, dev, red[o:o + self.nimg_f]),
+                              StashContract(self.pack_b, dev, red[o + self.nimg_f:o + self.nimg_f + self.nimg_b]))
         con_f, con_b = self._contract
         con_f.image.zero_()
         con_b.image.zero_()
@@ -663,16 +676,18 @@ class HipTrainStep:
         # With a process group the collective stays eager between two graphs (local part / tail + Adam).
         self.use_graph = bool(graph) and not self.engine.stash
         self._graphs = {}
+        self.last_ws = None
 
-    def step(self, u, y, noise, condition=True):
-        if self.use_graph:
-            return self._graph_step(u, y, noise, condition)
-        loss, grads, terms = self.engine.loss_and_grads(self.params, u, y, noise, condition)
+    def step(self, u, y, noise, condition=True, weight=1.0, local=False):
+        if self.use_graph and not local:
+            return self._graph_step(u, y, noise, condition, weight)
+        loss, grads, terms = self.engine.loss_and_grads(self.params, u, y, noise, condition, weight=weight, local=local)
         self.opt.step(grads)
         self.last_terms = terms
+        self.last_ws = self.engine.last_ws
         return loss
 
-    def _graph_step(self, u, y, noise, condition):
+    def _graph_step(self, u, y, noise, condition, weight=1.0):
         dev = self.engine.device
         u, y = _f64(u, dev), _f64(y, dev)
         key = (tuple(u.shape), tuple(y.shape), bool(condition))
@@ -722,7 +737,7 @@ class HipTrainStep:
                 self.opt._t = t_before
                 self.use_graph = False
                 return self.step(u, y, noise, condition)
-            g.update(graph=graph, front=front, state=state, loss=loss, terms=terms)
+            g.update(graph=graph, front=front, state=state, loss=loss, terms=terms, ws=state['ws'])
             self._graphs[key] = g
         else:
             g['u'].copy_(u)
@@ -731,9 +746,10 @@ class HipTrainStep:
                 g['noise'][k].copy_(_f64(noise[k], dev))
         if g['front'] is not None:
             g['front'].replay()
-            self.engine._grads_collective(g['state'])
+            self.engine._grads_collective(g['state'], weight)
         g['graph'].replay()
         self.opt._t += 1
         self.last_terms = g['terms']
+        self.last_ws = g['ws']            # the workspace THIS graph writes (a later eval pass may have moved engine.last_ws)
         return g['loss'].clone()
 

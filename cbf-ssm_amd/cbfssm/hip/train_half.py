@@ -195,7 +195,7 @@ class HipHalfGrad:
         z = torch.zeros((), dtype=torch.float64, device=self.device)
         return loss, {'loglik': loglik, 'kl_x': kl_x, 'entropy': z, 'kl_z_f': out[3], 'kl_z_b': z, 'info': out[7]}
 
-    def forward(self, params, u, y, noise, condition=True):
+    def forward(self, params, u, y, noise, condition=True, weight=1.0, local=False):
         dev = self.device
         p = {k: _f64(params[k], dev) for k in self.names}
         u, y = _f64(u, dev), _f64(y, dev)
@@ -206,13 +206,15 @@ class HipHalfGrad:
         self._forward(p, self._constrained(p), x0, u, y, _f64(noise['eps_f'], dev), prob, ws)
         self.last_ws = ws
         red2 = None
-        if self.dist is not None:
+        if self.dist is not None and not local:
             red2 = ws.out[0:2].clone()
+            if weight != 1.0:
+                red2.mul_(float(weight))
             all_reduce_sum(red2, self.dist)
         loss, terms = self._terms(ws, red2)
         return loss, terms, ws
 
-    def loss_and_grads(self, params, u, y, noise, condition=True):
+    def loss_and_grads(self, params, u, y, noise, condition=True, weight=1.0, local=False):
         lib = _l.load()
         dev = self.device
         p = {k: _f64(params[k], dev) for k in self.names}
@@ -295,12 +297,17 @@ class HipHalfGrad:
         if rnames:
             gl = torch.autograd.grad(x0g, [rp[k] for k in rnames], grad_outputs=gx0_b)
             rgrads = dict(zip(rnames, gl))
-        if self.dist is not None:
-            all_reduce_sum(red, self.dist)
-            if gB is not None:
-                all_reduce_sum(gB, self.dist)
-            for k in rgrads:
-                all_reduce_sum(rgrads[k], self.dist)
+        if self.dist is not None and not local:
+            # one flat buffer per step: [slab | data scalars | stash-mode K^-1-adjoint image | recognition-model gradients]
+            pieces = [red] + ([gB] if gB is not None else []) + [rgrads[k].reshape(-1) for k in rnames]
+            flat = torch.cat([t.reshape(-1) for t in pieces])
+            if weight != 1.0:
+                flat.mul_(float(weight))
+            all_reduce_sum(flat, self.dist)
+            o = 0
+            for t in pieces:
+                t.copy_(flat[o:o + t.numel()].view_as(t))
+                o += t.numel()
 
         grads = dict(rgrads)
         pre = self.pre

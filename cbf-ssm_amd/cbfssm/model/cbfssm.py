@@ -77,13 +77,8 @@ class CBFSSM(BaseModel):
         if self._engine is not None:
             return
         from ..hip.train import TFAdam
-        dist = None
-        try:
-            import torch.distributed as td
-            if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
-                dist = td
-        except ImportError:
-            pass
+        from ..hip.dist_utils import active
+        dist = active()
         self._dist = dist
         self._device = sess.device
         self._engine, names = self._make_engine(sess, dist)
@@ -94,11 +89,19 @@ class CBFSSM(BaseModel):
         seed = int(seed) if seed is not None else int.from_bytes(os.urandom(4), 'little')
         if dist is not None:
             # data parallel: same iteration order on every rank, each rank takes its shard of every mini-batch
-            from ..hip.dist_utils import broadcast_seed
+            from ..hip.dist_utils import broadcast_seed, broadcast_tensor
             seed = broadcast_seed(seed, dist)
             self._rng = np.random.default_rng(seed)
             self._rank, self._world = dist.get_rank(), dist.get_world_size()
             self._gen.manual_seed(seed + 7919 * (self._rank + 1))
+            # evaluations that are not sharded (predictions: every rank computes the whole batch) draw the same noise
+            # on every rank
+            self._gen_common = torch.Generator(device=sess.device)
+            self._gen_common.manual_seed(seed)
+            # the reference draws its initial inducing inputs / means unseeded (gp_tf.py:112-118): every rank has drawn
+            # its own in _setup_vars.  Rank 0's values win, also for a later `sess.run(model.init)`.
+            broadcast_tensor(self._opt.flat, dist, src=0)
+            self._init_values = {k: self._opt.views[k].detach().cpu().numpy().copy() for k in names}
         else:
             self._gen.manual_seed(seed)
 
@@ -124,13 +127,8 @@ class CBFSSM(BaseModel):
 
     def _stage_batch(self):
         data_in, data_out = self._next_batch()                      # raises OutOfRangeError at the end of the data
-        if self._dist is not None:
-            from ..hip.dist_utils import shard_range
-            lo, hi = shard_range(data_in.shape[0], self._rank, self._world)
-            if hi <= lo:
-                raise ValueError('mini-batch of %d sequences cannot be sharded over %d ranks'
-                                 % (data_in.shape[0], self._world))
-            data_in, data_out = data_in[lo:hi], data_out[lo:hi]
+        # (data parallel: the whole mini-batch is staged on every rank -- 7 MB at C3 -- and sharded on the device in
+        #  _execute, where the fetch list says whether this run is sharded at all)
         if getattr(self, '_upload', None) is None:
             self._upload = torch.cuda.Stream(device=self._device)
         # through page-locked staging buffers (two per shape, alternating: the copy of batch k+1 is asynchronous while
@@ -181,11 +179,17 @@ class CBFSSM(BaseModel):
             self._stepper = HipTrainStep(self.config, None, self._device, self._dist, engine=self._engine, opt=self._opt)
         return self._stepper if self._stepper.use_graph else None
 
-    def _draw_noise(self, B, T):
+    def _draw_noise(self, B, T, common=False):
         from ..hip.ops import NoisePipeline
+        if common:
+            if getattr(self, '_noise_common', None) is None:
+                self._noise_common = NoisePipeline(self._device, self._gen_common, self._noise_with_backward)
+            return self._noise_common.next(T, B * self.config['samples'])
         if getattr(self, '_noise', None) is None:
             self._noise = NoisePipeline(self._device, self._gen, self._noise_with_backward)
         return self._noise.next(T, B * self.config['samples'])
+
+    _SHARDED_FETCHES = frozenset(('train', 'loss', 'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b'))
 
     # ---- one sess.run
     def _execute(self, sess, names, feed):
@@ -203,20 +207,36 @@ class CBFSSM(BaseModel):
             raise KeyError('feed_dict must set model.condition (cbfssm.py:227)')
         condition = bool(feed['condition'])
         u, y = self._device_batch()
+        # Data parallel: runs that fetch only the loss (and `train`) shard the mini-batch over the ranks and exchange one
+        # all-reduce; runs that fetch per-sequence results (pred_mean, x_final, ...) are evaluated whole on every rank,
+        # without a collective and with rank-invariant noise, so every rank holds the same result.  A rank whose shard is
+        # empty (fewer sequences than ranks: run_sarcos.py has batch_size 5, a partial last batch) evaluates a one-
+        # sequence stand-in with weight 0 and still joins the collective.
+        kw = {}
+        sharded = self._dist is not None and all(n in self._SHARDED_FETCHES for n in names)
+        if sharded:
+            from ..hip.dist_utils import shard_range
+            lo, hi = shard_range(u.shape[0], self._rank, self._world)
+            if hi <= lo:
+                lo, hi, kw = 0, 1, {'weight': 0.0}
+            u, y = u[lo:hi].contiguous(), y[lo:hi].contiguous()
+        elif self._dist is not None:
+            kw = {'local': True}
         B, T = u.shape[0], u.shape[1]
-        noise = self._draw_noise(B, T)
+        noise = self._draw_noise(B, T, common=(self._dist is not None and not sharded))
         eng = self._engine
         if 'train' in names:
             stepper = self._train_stepper()
             if stepper is not None:                       # loss, gradient and Adam update as HIP graph replays
-                loss = stepper.step(u, y, noise, condition)
+                loss = stepper.step(u, y, noise, condition, **kw)
                 terms = stepper.last_terms
+                ws = stepper.last_ws
             else:
-                loss, grads, terms = eng.loss_and_grads(self._opt.views, u, y, noise, condition)
+                loss, grads, terms = eng.loss_and_grads(self._opt.views, u, y, noise, condition, **kw)
                 self._opt.step(grads)                                                                 # cbfssm.py:275
-            ws = eng.last_ws
+                ws = eng.last_ws
         else:
-            loss, terms, ws = eng.forward(self._opt.views, u, y, noise, condition)
+            loss, terms, ws = eng.forward(self._opt.views, u, y, noise, condition, **kw)
         self._stage_ahead()     # the next mini-batch: gathered and uploaded while the device works on this one
         # one device-to-host transfer for everything scalar that this run fetches (each .item() is a stream sync)
         scal_names = [k for k in ('loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b') if k in names]

@@ -44,6 +44,24 @@ class Session:
                 raise RuntimeError('cbfssm needs an MI355X: no HIP device is visible and there is no CPU fallback')
             device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', '0'))
         self.device = torch.device(device)
+        self._init_process_group()
+
+    def _init_process_group(self):
+        """Under `python -m torch.distributed.run ... run/run_*.py` (WORLD_SIZE > 1 in the environment) the first
+        Session brings up the process group: one process per GPU, backend nccl = RCCL over xGMI (CBFSSM_DIST_BACKEND
+        overrides: the tests use gloo)."""
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        if world <= 1 or self.device.type != 'cuda':
+            return
+        import torch.distributed as td
+        if not td.is_available() or td.is_initialized():
+            return
+        torch.cuda.set_device(self.device)
+        backend = os.environ.get('CBFSSM_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            td.init_process_group('nccl', device_id=self.device)
+        else:
+            td.init_process_group(backend)
 
     def __enter__(self):
         return self
@@ -72,8 +90,12 @@ class Saver:
         self.model = model
 
     def save(self, sess, path):
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save(self.model._state_dict(), path)
+        # data parallel: the ranks hold identical parameters; rank 0 writes, the others wait until the file is there
+        from ..hip.dist_utils import is_writer, barrier
+        if is_writer():
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            torch.save(self.model._state_dict(), path)
+        barrier()
 
     def restore(self, sess, path):
         sd = torch.load(path, map_location='cpu', weights_only=True)

@@ -14,7 +14,8 @@ class OutputSummary:
         self.rmse_all = []
         os.makedirs(out_dir, exist_ok=True)
         script = sys.argv[0] if sys.argv else ''
-        if script and os.path.isfile(script):
+        self._writer = int(os.environ.get('RANK', '0')) == 0      # data parallel: rank 0 writes the files
+        if script and os.path.isfile(script) and self._writer:
             shutil.copyfile(os.path.abspath(script), os.path.join(out_dir, 'main.py'))
 
     def add_outputs(self, outputs):
@@ -29,5 +30,7 @@ class OutputSummary:
         lines = ['RMSE', '====', '', 'Runs:']
         lines += ['  %f' % v for v in values]
         lines += ['Mean: %f' % values.mean(), 'Std:  %f' % values.std()]
+        if not self._writer:
+            return
         with open(os.path.join(self.out_dir, 'summary.txt'), 'w') as fh:
             fh.write('\n'.join(lines) + '\n')

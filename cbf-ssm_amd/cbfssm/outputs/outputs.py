@@ -15,6 +15,7 @@ import numpy as np
 from scipy.io import savemat
 
 from ..model.session import Session
+from ..hip.dist_utils import is_writer
 
 try:                                        # figures are optional: the numbers do not depend on matplotlib
     import matplotlib
@@ -75,7 +76,7 @@ class Outputs:
 
     # ---- training curve
     def training_stats(self):
-        if self.trainer is None or plt is None:
+        if self.trainer is None or plt is None or not is_writer():
             return
         print("  training stats")
         fig = plt.figure(1)
@@ -98,6 +99,8 @@ class Outputs:
         mean = ds.denormalize(mean_n, 'out')[0]
         std = ds.denormalize(np.sqrt(var_n), 'out', shift=False)[0]
         truth = ds.denormalize(first_out, 'out')[0]
+        if not is_writer():          # data parallel: every rank computes the same prediction, rank 0 writes the files
+            return
         savemat(self._path('predict_%s.mat' % tag), {'mean': mean, 'std': std, 'gt': truth})
         if plt is None:
             return
@@ -131,6 +134,8 @@ class Outputs:
             per_experiment.append(np.mean(err * err))            # mean over time and output dims, uniform weights
         mse = float(np.mean(per_experiment))
         self.last_rmse = float(np.sqrt(mse))
+        if not is_writer():
+            return
         with open(self._path('mse.txt'), 'w') as fh:
             fh.write("MSE:  %f\nRMSE: %f\n" % (mse, self.last_rmse))
 
@@ -138,6 +143,8 @@ class Outputs:
     def var_dump(self, sess):
         print("  var dump")
         m = self.model
+        if not is_writer():
+            return
         with open(self._path('var_dump.txt'), 'w') as fh:
             for name, fetch in m.var_dict.items():
                 value = np.asarray(sess.run(fetch, feed_dict={m.condition: False}))

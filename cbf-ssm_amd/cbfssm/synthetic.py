@@ -142,6 +142,34 @@ def perturb_params(p, seed=3, scale=0.2):
     return {k: v + scale * rng.standard_normal(v.shape) * (0.2 if 'zeta_mean' in k else 1.0) for k, v in p.items()}
 
 
+def softplus(x):
+    """numpy softplus(x) + 1e-10 (cbfssm/model/tf_transform.py:19-21)."""
+    return np.logaddexp(0.0, np.asarray(x, dtype=np.float64)) + 1e-10
+
+
+def trained_like_params(w: Workload, ls_mult=4.0, zeta_mean=0.5, zeta_var=1e-2, cluster=1.0, seed=5):
+    """Parameters of the kind training moves towards, for the conditioning sweep of the parity tests: lengthscales
+    multiplied by `ls_mult` and inducing inputs contracted by `cluster` (correlated inducing points => K_mm
+    ill-conditioned, the 1e-8 jitter of gp_tf.py:57,130 starts to matter), inducing means of order `zeta_mean` (the GP
+    carries the dynamics), inducing variances log-uniform around `zeta_var` (one decade)."""
+    pn = perturb_params(make_params(w, seed=1), scale=0.1)
+    rng = np.random.default_rng(seed)
+    for g in 'fb':
+        pn[g + '.lengthscales_unc'] = softplus_inverse(softplus(pn[g + '.lengthscales_unc']) * ls_mult)
+        pn[g + '.zeta_mean'] = zeta_mean * rng.standard_normal(pn[g + '.zeta_mean'].shape)
+        pn[g + '.zeta_var_unc'] = softplus_inverse(zeta_var * np.exp(rng.uniform(-1.15, 1.15, pn[g + '.zeta_var_unc'].shape)))
+        pn[g + '.zeta_pos'] = pn[g + '.zeta_pos'] * cluster
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in pn.items()}
+
+
+def kmm_condition(p, g, jitter=1e-8):
+    """2-norm condition number of K_mm + jitter I of GP `g` ('f' or 'b') at parameters p (host numpy; test helper)."""
+    Z = p[g + '.zeta_pos'] / softplus(p[g + '.lengthscales_unc'])
+    zs = np.sum(Z * Z, 1)
+    K = softplus(p[g + '.variance_unc']) * np.exp(-0.5 * (-2.0 * Z @ Z.T + zs[:, None] + zs[None, :]))
+    return float(np.linalg.cond(K + jitter * np.eye(K.shape[0])))
+
+
 def make_inputs(w: Workload, seed=0):
     """u (B,T,dim_u), y (B,T,dim_y) ~ N(0,1): the reference z-normalises its data (datasets/base_ds.py:25-34)."""
     rng = np.random.default_rng(seed)

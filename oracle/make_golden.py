@@ -59,6 +59,49 @@ def main():
         print(name, os.path.getsize(path) // 1024, 'KiB', 'loss', blob['c1_loss'])
 
 
+# Full-length recurrences at reduced batch: the shapes BASELINE.json quotes its tolerance on (T = 250 / 1000 / 100 with
+# the configured S, M, recog_len), B cut to what the oracle and the autograd restatement finish in seconds.
+FULL_CASES = {
+    'full_C2': dict(base='C2', B=4),      # Actuator: M=50  T=100  S=50 R=16
+    'full_C3': dict(base='C3', B=2),      # Sarcos:   M=100 T=250  S=20 R=16
+    'full_C4': dict(base='C4', B=2),      # Sarcos:   M=200 T=250  S=20 R=16
+    'full_C5': dict(base='C5', B=1),      # RoboMove: M=300 T=1000 S=50 R=50
+}
+T_STRIDE = 8      # x_final / y_tilde are stored at every 8th step and at the last one (the recurrence carries every
+                  # earlier error into those; pred_mean / pred_var are stored in full)
+
+
+def main_full():
+    import dataclasses
+    out_dir = os.path.join(ROOT, 'tests', 'golden')
+    for name, spec in FULL_CASES.items():
+        w = dataclasses.replace(syn.WORKLOADS[spec['base']], B=spec['B'], name=name)
+        cfg = w.model_config()
+        p = syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)
+        u, y = syn.make_inputs(w, seed=0)
+        noise = syn.make_noise(w, seed=2)
+        blob = {'workload_' + k: np.asarray(v) for k, v in syn.workload_dict(w).items() if k != 'name'}
+        blob.update({'param_' + k: v for k, v in p.items()})
+        blob.update({'u': u, 'y': y})
+        blob.update({'noise_' + k: v for k, v in noise.items()})
+        tsel = np.unique(np.concatenate((np.arange(0, w.T, T_STRIDE), [w.T - 1])))
+        blob['t_sel'] = tsel
+        for cond in (True, False):
+            tag = 'c1_' if cond else 'c0_'
+            res = orc.elbo_step(cfg, p, u, y, noise, cond)
+            for k in ('loss', 'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b', 'pred_mean', 'pred_var'):
+                blob[tag + k] = np.asarray(res[k])
+            blob[tag + 'x_final_sel'] = np.asarray(res['x_final'][:, tsel])
+            blob[tag + 'y2_sel'] = np.asarray(res['y_tilde'][:, tsel][..., w.dim_y:])
+            if cond:
+                scal, grads = tref.loss_and_grads(cfg, p, u, y, noise, cond)
+                assert abs(scal['loss'] - res['loss']) <= 1e-9 * abs(res['loss'])
+                blob.update({tag + 'grad_' + k: g for k, g in grads.items()})
+        path = os.path.join(out_dir, name + '.npz')
+        np.savez_compressed(path, **blob)
+        print(name, os.path.getsize(path) // 1024, 'KiB', 'loss', blob['c1_loss'], flush=True)
+
+
 def main_half():
     """CBFSSMHALF fixture (cbfssm/model/cbfssmhalf.py): GRU recognition model, both `condition` settings."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -81,5 +124,9 @@ def main_half():
 
 
 if __name__ == '__main__':
-    main()
-    main_half()
+    if len(sys.argv) > 1 and sys.argv[1] == 'full':
+        main_full()
+    else:
+        main()
+        main_half()
+        main_full()

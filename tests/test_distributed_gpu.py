@@ -106,3 +106,154 @@ def test_data_parallel_step_graphs_equal_eager():
         for k in train.PARAM_NAMES:
             np.testing.assert_array_equal(pg[k], pe[k])
             np.testing.assert_array_equal(pg[k], out[0][True][1][k])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stash-mode tile (M > 112): the contracted K^-1-adjoint images ride in the same flat buffer -> still ONE all-reduce
+# ---------------------------------------------------------------------------------------------------------------------
+def _stash_case():
+    from cbfssm import synthetic as syn
+    w = syn.tiny(M=130, dim_x=9, dim_u=3, dim_y=2, T=13, B=4, S=6, recog_len=3)
+    return w, syn.perturb_params(syn.make_params(w), scale=0.1), syn.make_inputs(w), syn.make_noise(w)
+
+
+def _stash_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from cbfssm.hip import train
+        from cbfssm.hip.dist_utils import shard_range
+        w, p, (u, y), noise = _stash_case()
+        lo, hi = shard_range(w.B, rank, world)
+        nz = {'hid_b': noise['hid_b'][:, :, lo:hi], 'eps_b': noise['eps_b'][:, :, lo:hi],
+              'eps_f': noise['eps_f'][:, lo:hi]}
+        nz = {k: np.ascontiguousarray(v) for k, v in nz.items()}
+        eng = train.HipElboGrad(w.model_config(), 'cuda:0', dist)
+        assert eng.stash
+        calls = []
+        orig = dist.all_reduce
+
+        def counting(t, *a, **k):
+            calls.append(int(t.numel()))
+            return orig(t, *a, **k)
+        dist.all_reduce = counting
+        try:
+            params = {k: torch.tensor(v, device='cuda:0') for k, v in p.items()}
+            loss, grads, _ = eng.loss_and_grads(params, u[lo:hi], y[lo:hi], nz)
+        finally:
+            dist.all_reduce = orig
+        out[rank] = (float(loss), {k: g.cpu().numpy() for k, g in grads.items()}, calls, int(eng.red.numel()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_stash_mode_step_is_one_allreduce_and_equals_global_batch():
+    from cbfssm.hip import train
+    w, p, (u, y), noise = _stash_case()
+    eng = train.HipElboGrad(w.model_config(), 'cuda:0')
+    params = {k: torch.tensor(v, device='cuda:0') for k, v in p.items()}
+    loss, grads, _ = eng.loss_and_grads(params, u, y, noise)
+    ref = (float(loss), {k: g.cpu().numpy() for k, g in grads.items()})
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_stash_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        l, g, calls, nred = out[rank]
+        assert calls == [nred], calls                       # exactly one collective, over the whole flat buffer
+        assert l == pytest.approx(ref[0], rel=1e-10)
+        for k in train.PARAM_NAMES:
+            np.testing.assert_allclose(g[k], ref[1][k], rtol=1e-8, atol=1e-9 * np.abs(ref[1][k]).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL itself: backend "nccl" with one rank all-reduces the real flat float64 buffer on the device
+# ---------------------------------------------------------------------------------------------------------------------
+def _nccl_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0),
+                            timeout=datetime.timedelta(seconds=120))
+    try:
+        from cbfssm.hip import train
+        w, p, (u, y), noise = _case()
+        eng = train.HipElboGrad(w.model_config(), 'cuda:0', None)
+        params = {k: torch.tensor(v, device='cuda:0') for k, v in p.items()}
+        state = eng._grads_local(params, u, y, noise)
+        before = eng.red.clone()
+        dist.all_reduce(eng.red)                            # RCCL sum over the one rank: the buffer must come back as is
+        torch.cuda.synchronize()
+        same = bool(torch.equal(before, eng.red))
+        loss, grads, _ = eng._grads_finish(state)
+        out[0] = (same, float(loss), dist.get_backend(), int(eng.red.numel()), str(eng.red.dtype))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_allreduce_accepts_the_flat_f64_buffer():
+    from cbfssm.hip import train
+    w, p, (u, y), noise = _case()
+    eng = train.HipElboGrad(w.model_config(), 'cuda:0')
+    params = {k: torch.tensor(v, device='cuda:0') for k, v in p.items()}
+    loss, _, _ = eng.loss_and_grads(params, u, y, noise)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    same, l, backend, n, dt = out[0]
+    assert backend == 'nccl' and same and dt == 'torch.float64' and n > 1000
+    assert l == pytest.approx(float(loss), rel=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the drop-in flow itself under two ranks: Trainer + Outputs through cbfssm.model.CBFSSM, NO seed in the config (every
+# rank draws its own initial values, as the reference's unseeded numpy initialisers would), mini-batches that leave a
+# rank without a sequence
+# ---------------------------------------------------------------------------------------------------------------------
+def _dropin_worker(rank, world, port, root_dir, out):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'WORLD_SIZE': str(world),
+                       'RANK': str(rank), 'LOCAL_RANK': '0', 'CBFSSM_DIST_BACKEND': 'gloo'})
+    try:
+        from cbfssm.datasets import make_synthetic_ds
+        from cbfssm.training import Trainer
+        from cbfssm.outputs import Outputs
+        from cbfssm.model import CBFSSM
+        ds_sel = make_synthetic_ds(dim_u=1, dim_y=1, n_train=400, n_test=160, seed=1)
+        dim_x = 3
+        cfg = {'ds': ds_sel, 'batch_size': 3, 'shuffle': 10000,                     # no 'seed'
+               'dim_x': dim_x, 'ind_pnt_num': 20, 'samples': 10, 'learning_rate': 0.05,
+               'loss_factors': np.asarray([1., 0.]), 'k_factor': 5., 'recog_len': 8,
+               'zeta_pos': 2., 'zeta_mean': 0.05 ** 2, 'zeta_var': 0.01 ** 2,
+               'var_x': np.asarray([0.002 ** 2] * dim_x), 'var_y': np.asarray([1. ** 2] * dim_x),
+               'gp_var': 0.5 ** 2, 'gp_len': 2.}
+        ds = ds_sel(40, 20)                    # 19 training windows: six mini-batches of 3 and a last one of 1
+        assert ds.train_in_batch.shape[0] % 3 == 1
+        model = CBFSSM(cfg)
+        own_draw = model._init_values['f.zeta_pos'].copy()
+        outputs = Outputs(root_dir)
+        outputs.set_ds(ds)
+        outputs.set_model(model, root_dir)
+        trainer = Trainer(model, root_dir)
+        trainer.train(ds, 2)
+        outputs.set_trainer(trainer)
+        outputs.create_all()
+        out[rank] = (own_draw, model._opt.flat.cpu().numpy(), list(trainer.train_all), list(trainer.test_all),
+                     outputs.get_last_rmse())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_dropin_flow_two_ranks_unseeded(tmp_path):
+    root_dir = str(tmp_path / 'exp')
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dropin_worker, args=(2, _free_port(), root_dir, out), nprocs=2, join=True)
+    d0, p0, tr0, te0, rm0 = out[0]
+    d1, p1, tr1, te1, rm1 = out[1]
+    assert not np.array_equal(d0, d1)                       # the ranks did draw different initial values ...
+    np.testing.assert_array_equal(p0, p1)                   # ... and still hold identical parameters after training
+    assert tr0 == tr1 and te0 == te1 and rm0 == rm1
+    assert all(np.isfinite(tr0)) and np.isfinite(rm0)
+    for f in ('best.ckpt', 'model.ckpt', 'mse.txt', 'var_dump.txt', 'predict_train.mat', 'predict_test.mat'):
+        assert os.path.isfile(os.path.join(root_dir, f)), f
