@@ -40,6 +40,25 @@ def _cpu_model():
     return 'unknown'
 
 
+def _usable_cores():
+    """CPUs this process may actually run on: affinity mask and cgroup quota (a GPU box hands one GPU's share of the
+    host's cores to the job; asking the thread pools for every core the host shows would oversubscribe it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(w, mode='eval', full=False):
     """The op-for-op PyTorch-CPU float64 restatement (oracle/cbfssm_torch_ref.py) of the reference's TF-1.8 graph, timed
     on this box's host cores (BASELINE.md section 2 / SURVEY.md section 8d) on a BOUNDED sample of the same workload:
@@ -51,7 +70,10 @@ def cpu_baseline(w, mode='eval', full=False):
     from cbfssm import synthetic as syn
     from oracle import cbfssm_torch_ref as tref
     import dataclasses
-    ncores = os.cpu_count() or 1
+    host_cores = os.cpu_count() or 1
+    usable = _usable_cores()
+    # "all cores" = what the job can use, at most CBFSSM_BENCH_THREADS (16 = one GPU's CPU share on the MI355X boxes)
+    ncores = max(1, min(usable, int(os.environ.get('CBFSSM_BENCH_THREADS', '16'))))
     try:
         torch.set_num_interop_threads(10)                    # trainer.py:25 (can only be set once per process)
     except RuntimeError:
@@ -87,13 +109,14 @@ def cpu_baseline(w, mode='eval', full=False):
     scale = calls(w.T) / calls(T_s)
     per_call_ratio = (t_all / calls(T_s)) / (t8 / calls(T_0))
     best = min(t_all, t_ref) * scale
-    return {'value': 1.0 / best, 'unit': 'steps/s', 'cores': ncores, 'cpu_model': _cpu_model(), 'kind': 'port',
+    return {'value': 1.0 / best, 'unit': 'steps/s', 'cores': host_cores, 'cores_usable': usable, 'cpu_model': _cpu_model(),
+            'kind': 'port',
             'threads': {'all_cores': {'intra_op': ncores, 'seconds_per_step': t_all * scale},
                         'reference_session_config': {'intra_op': 5, 'inter_op': 10, 'seconds_per_step': t_ref * scale}},
             'sample_T': T_s, 'sample_gp_calls': calls(T_s), 'full_gp_calls': calls(w.T), 'extrapolated': T_s != w.T,
             'linearity_T%d_vs_T%d_per_call' % (T_s, T_0): per_call_ratio,
             'sample': '%s step of %s, every size as configured (M=%d B=%d S=%d recog_len=%d), T = %d of %d (%d of %d GP '
-                      'calls): %.2f s on all %d cores, %.2f s with the reference session config (5 intra-op / 10 '
+                      'calls): %.2f s on %d threads (the job\'s share of the host\'s cores), %.2f s with the reference session config (5 intra-op / 10 '
                       'inter-op threads)%s; time per GP call at T=%d is %.2fx that at T=%d; PyTorch-CPU float64 '
                       'restatement of the TF-1.8 op sequence%s; value = the faster of the two settings'
                       % (mode, w.name, w.M, w.B, w.S, w.recog_len, T_s, w.T, calls(T_s), calls(w.T), t_all, ncores, t_ref,

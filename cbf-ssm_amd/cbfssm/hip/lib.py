@@ -9,7 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CBFSSM_HIP_LIB') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libcbfssm_hip.so'))
 
-SCAL_SIGMA2, SCAL_LOGDET, SCAL_KLZ, SCAL_INFO, SCAL_COUNT = 0, 1, 2, 3, 8
+SCAL_SIGMA2, SCAL_LOGDET, SCAL_KLZ, SCAL_INFO, SCAL_COND, SCAL_COUNT = 0, 1, 2, 3, 4, 16
+GP_FORM_DENSE, GP_FORM_TRI = 0, 1
 JITTER = 1e-8   # cbfssm/model/gp_tf.py:57
 
 # every symbol include/cbfssm_hip.h declares (tests check the shared object exports all of them)
@@ -31,8 +32,9 @@ class ParamLayout(C.Structure):
 
 class PackLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ('total', 'Bp', 'Zp', 'cz', 'muA', 's2A', 'invl', 'scal', 'Kmm', 'L', 'Kinv',
-                                          'Linvt', 'Zs', 'muB', 's2B', 'ZT', 'rev_slab', 'work')] + \
-               [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS', 'JB', 'rev_stash')]
+                                          'Linvt', 'Zs', 'muB', 's2B', 'ZT', 'rev_slab', 'work', 'Wp', 'WTp')] + \
+               [(n, C.c_int32) for n in ('M', 'D', 'Do', 'NBLK', 'DK', 'Mp', 'Dp', 'KS', 'JB', 'rev_stash', 'gp_form',
+                                         'reserved')]
 
 
 class Problem(C.Structure):

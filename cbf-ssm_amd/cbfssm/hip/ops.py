@@ -25,13 +25,73 @@ def _f64(t, device):
     return torch.as_tensor(t, dtype=torch.float64, device=device).contiguous()
 
 
+def gp_form_mode(config=None):
+    """'dense' | 'tri' | 'auto' (config['gp_form'] or CBFSSM_GP_FORM; default auto): which form of GPModel.predict the pass
+    kernels run.  dense: A2 = K^-1 k in one product, fvar_0 = sigma^2 - k.A2.  tri: the reference's own order
+    (gp_tf.py:137-145), A = L^-1 k, fvar_0 = sigma^2 - |A|^2, A2 = L^-T A as two triangular products.  auto: dense while
+    the measured condition number of K_mm + jitter I stays below CBFSSM_GP_FORM_COND (1e5), tri above."""
+    mode = None
+    if config is not None:
+        mode = config.get('gp_form')
+    mode = mode or os.environ.get('CBFSSM_GP_FORM', 'auto')
+    if mode not in ('dense', 'tri', 'auto'):
+        raise ValueError("gp_form must be 'dense', 'tri' or 'auto', not %r" % (mode,))
+    return mode
+
+
 class GPPack:
     """Loop-invariant operands of one GPModel on the device (include/cbfssm_hip.h: cbfssm_gp_prepare_f64)."""
 
-    def __init__(self, M, D, Do, device):
+    def __init__(self, M, D, Do, device, form_mode=None):
         self.layout = _l.pack_layout(M, D, Do)
         self.M, self.D, self.Do = M, D, Do
         self.buf = torch.zeros(self.layout.total, dtype=torch.float64, device=device)
+        self.form_mode = form_mode or gp_form_mode()
+        self.cond_threshold = float(os.environ.get('CBFSSM_GP_FORM_COND', 1e5))
+        self.layout.gp_form = _l.GP_FORM_TRI if self.form_mode == 'tri' else _l.GP_FORM_DENSE
+        self._cond_host = None          # pinned landing slot of the asynchronous condition-number read-back
+        self._cond_ev = None
+        self._decided = self.form_mode != 'auto'
+        self.last_cond = None
+
+    # ---- form policy (auto mode).  The condition number comes out of the prepare kernel on the device; reading it is an
+    # asynchronous copy into pinned memory, consumed when its event has completed -- by the time the parameters have
+    # moved enough to matter that is a step or two late, and no step waits for the host.  Only the very first decision
+    # blocks (there is nothing older to go by).
+    def gp_form(self):
+        return 'tri' if self.layout.gp_form == _l.GP_FORM_TRI else 'dense'
+
+    def _consume_cond(self):
+        cond = float(self._cond_host[0])
+        self.last_cond = cond
+        thr = self.cond_threshold
+        tri = self.layout.gp_form == _l.GP_FORM_TRI
+        # (hysteresis: a factor four between switching up and switching back, every switch is another captured graph)
+        if not (cond == cond) or cond > thr:
+            tri = True
+        elif cond < 0.25 * thr:
+            tri = False
+        self.layout.gp_form = _l.GP_FORM_TRI if tri else _l.GP_FORM_DENSE
+        self._decided = True
+        self._cond_ev = None
+
+    def update_form(self, blocking=False):
+        """Consume a completed condition-number read-back (it may flip the form), start the next one; returns the form
+        the next launches run.  `blocking`: wait for the read-back of the latest prepare."""
+        if self.form_mode != 'auto' or torch.cuda.is_current_stream_capturing():
+            return self.gp_form()
+        if self._cond_ev is not None and self._cond_ev.query():
+            self._consume_cond()
+        if self._cond_ev is None:
+            if self._cond_host is None:
+                self._cond_host = torch.zeros(1, dtype=torch.float64).pin_memory()
+            self._cond_host.copy_(self.scal[_l.SCAL_COND:_l.SCAL_COND + 1], non_blocking=True)
+            self._cond_ev = torch.cuda.Event()
+            self._cond_ev.record()
+        if blocking or not self._decided:
+            self._cond_ev.synchronize()
+            self._consume_cond()
+        return self.gp_form()
 
     def prepare(self, Z, lengthscales, variance, zeta_mean, zeta_var, jitter=_l.JITTER):
         dev = self.buf.device
@@ -42,6 +102,7 @@ class GPPack:
         rc = _l.load().cbfssm_gp_prepare_f64(C.byref(self.layout), _ptr(Z), _ptr(ls), _ptr(var), _ptr(zm), _ptr(zv),
                                              float(jitter), _ptr(self.buf), _stream())
         _l.check(rc, 'cbfssm_gp_prepare_f64')
+        self.update_form()                      # (blocks for the very first decision only)
         return self
 
     def section(self, name, shape):
@@ -94,6 +155,8 @@ def prepare_pair(pack0, args0, pack1, args1, jitter=_l.JITTER):
         ptrs += [C.byref(pack.layout), _ptr(Z), _ptr(ls), _ptr(var), _ptr(zm), _ptr(zv), _ptr(pack.buf)]
     rc = _l.load().cbfssm_gp_prepare2_f64(*ptrs, float(jitter), _stream())
     _l.check(rc, 'cbfssm_gp_prepare2_f64')
+    for pack in (pack0, pack1):
+        pack.update_form()
 
 
 def kmm_chol(Z, lengthscales, variance, jitter=_l.JITTER):
@@ -213,15 +276,21 @@ class HipElbo:
         self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
         self.M, self.S = config['ind_pnt_num'], config['samples']
         D = self.dim_x + self.dim_u
-        self.pack_f = GPPack(self.M, D, self.dim_x, self.device)
-        self.pack_b = GPPack(self.M, D, self.dim_x - self.dim_y, self.device)
+        mode = gp_form_mode(config)
+        self.pack_f = GPPack(self.M, D, self.dim_x, self.device, mode)
+        self.pack_b = GPPack(self.M, D, self.dim_x - self.dim_y, self.device, mode)
         self._ws = {}
+
+    def gp_form(self):
+        return self.pack_f.gp_form() + '/' + self.pack_b.gp_form()
 
     def prepare(self, params):
         p = {k: _f64(v, self.device) for k, v in params.items()}
         args = [(p[g + '.zeta_pos'], tf_forward(p[g + '.lengthscales_unc']), tf_forward(p[g + '.variance_unc']),
                  p[g + '.zeta_mean'], tf_forward(p[g + '.zeta_var_unc'])) for g in 'fb']
         prepare_pair(self.pack_f, args[0], self.pack_b, args[1])
+        for pk in (self.pack_f, self.pack_b):
+            pk.update_form(blocking=True)       # an explicit prepare(): the evaluation that follows uses THIS K_mm's form
         self.var_x = tf_forward(p['var_x_unc']).contiguous()
         self.var_y = tf_forward(p['var_y_unc']).contiguous()
 

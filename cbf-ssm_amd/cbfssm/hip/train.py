@@ -93,8 +93,9 @@ class HipElboGrad:
         self.M, self.S = config['ind_pnt_num'], config['samples']
         self.D = self.dim_x + self.dim_u
         self.dob = self.dim_x - self.dim_y
-        self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device)
-        self.pack_b = GPPack(self.M, self.D, self.dob, self.device)
+        mode = ops.gp_form_mode(config)
+        self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device, mode)
+        self.pack_b = GPPack(self.M, self.D, self.dob, self.device, mode)
         self.has_adjoint = all(pk.layout.rev_slab > 0 for pk in (self.pack_f, self.pack_b))
         # tile heights above 112 inducing points run the adjoint in "stash mode" (include/cbfssm_hip.h)
         self.stash = bool(self.pack_f.layout.rev_stash)
@@ -123,6 +124,10 @@ class HipElboGrad:
         if self.has_adjoint:
             nw = int(_l.load().cbfssm_train_tail_work_elems(C.byref(self.pack_f.layout), C.byref(self.pack_b.layout)))
             self.tail_work = torch.zeros(max(nw, 1), **f)
+
+    def gp_forms(self):
+        """the GP forms the next launches will run, after consuming any completed condition-number read-back"""
+        return tuple(pk.update_form() for pk in (self.pack_f, self.pack_b))
 
     def _need_adjoint(self):
         if not self.has_adjoint:
@@ -690,7 +695,9 @@ class HipTrainStep:
     def _graph_step(self, u, y, noise, condition, weight=1.0):
         dev = self.engine.device
         u, y = _f64(u, dev), _f64(y, dev)
-        key = (tuple(u.shape), tuple(y.shape), bool(condition))
+        # (auto form: a completed condition-number read-back may flip the GP form -- a different set of kernels, so a
+        #  different graph)
+        key = (tuple(u.shape), tuple(y.shape), bool(condition), self.engine.gp_forms())
         g = self._graphs.get(key)
         names = ('hid_b', 'eps_b', 'eps_f')
         if g is None:
@@ -700,7 +707,9 @@ class HipTrainStep:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                self.engine.loss_and_grads(self.params, g['u'], g['y'], g['noise'], condition)
+                # (without the collective: the ranks do not capture in the same step -- a rank sees a new shard shape
+                #  when the others replay -- so a warm-up all-reduce would be one collective too many on this rank)
+                self.engine.loss_and_grads(self.params, g['u'], g['y'], g['noise'], condition, local=True)
             cur.wait_stream(side)
             eng = self.engine
             front = None

@@ -189,6 +189,37 @@ class CBFSSM(BaseModel):
             self._noise = NoisePipeline(self._device, self._gen, self._noise_with_backward)
         return self._noise.next(T, B * self.config['samples'])
 
+    def run_experiments(self, sess, fetch, data_in, data_out, feed_dict):
+        """What `for k: load_ds(in[k:k+1], out[k:k+1]); run(sess, fetch, feed)` returns (outputs/outputs.py:121-133 of the
+        reference loops over the test experiments that way, one B = 1 `sess.run` each: 2 workgroups on a 256-CU part), as
+        ONE launch over all experiments: they are rows of one array, hence of equal length, and sequences never
+        interact.  Every experiment gets the noise the k-th run of that loop would have drawn (same generator, same
+        order), so the results are the loop's results.  Returns a list with one array per experiment."""
+        self._ensure(sess)
+        name = fetch.name
+        if name not in ('pred_mean', 'pred_var', 'internal_mean', 'internal_var'):
+            raise KeyError('run_experiments serves the per-sequence prediction fetches, not %r' % (name,))
+        feed = {(k.name if hasattr(k, 'name') else k): v for k, v in feed_dict.items()}
+        condition = bool(feed['condition'])
+        data_in = np.ascontiguousarray(data_in, dtype=np.float64)
+        data_out = np.ascontiguousarray(data_out, dtype=np.float64)
+        n, T = data_in.shape[0], data_in.shape[1]
+        S = self.config['samples']
+        common = self._dist is not None
+        draws = [{k: v.clone() for k, v in self._draw_noise(1, T, common=common).items()} for _ in range(n)]
+        noise = {}
+        for k in draws[0]:
+            lead = 2 if k in ('hid_b', 'eps_b') else 1
+            noise[k] = torch.cat([d[k].view(lead, -1, S) for d in draws], dim=2).contiguous()     # chain c = b S + s
+        u = torch.as_tensor(data_in, device=self._device)
+        y = torch.as_tensor(data_out, device=self._device)
+        kw = {'local': True} if self._dist is not None else {}
+        loss, terms, ws = self._engine.forward(self._opt.views, u, y, noise, condition, **kw)
+        if float(terms['info']) != 0.0:
+            raise InvalidArgumentError('Cholesky decomposition was not successful')
+        res = getattr(ws, {'internal_mean': 'int_mean', 'internal_var': 'int_var'}.get(name, name)).cpu().numpy()
+        return [res[k:k + 1] for k in range(n)]
+
     _SHARDED_FETCHES = frozenset(('train', 'loss', 'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b'))
 
     # ---- one sess.run

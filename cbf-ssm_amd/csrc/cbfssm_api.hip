@@ -67,6 +67,8 @@ struct PrepArgs {
     double* s2B;
     double* ZT;
     int JB;
+    double* Wp;            // triangular operand images (two-triangular GP form)
+    double* WTp;
     double* info_out;      // kmm_chol: 1 double
 };
 
@@ -310,11 +312,36 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
         const int row = 16 * rb + (l & 15), col = 4 * s + (l >> 4);
         a.Bp[i] = (row < M && col < M) ? Cm[row * M + col] : 0.0;
     }
+    // W = L^-1 = G^T (G = L^-T, upper triangular, in a.Gout) and W^T = G as A-operand images of the two triangular
+    // products A = W K, A2 = W^T A (gp_tf.py:137,145); the kernels skip the zero blocks
+    for (int i = tid; i < NBLK * KS * 64; i += PREP_NT) {
+        const int l = i & 63, s = (i >> 6) % KS, rb = (i >> 6) / KS;
+        const int row = 16 * rb + (l & 15), col = 4 * s + (l >> 4);
+        const bool in = row < M && col < M;
+        a.Wp[i] = (in && col <= row) ? a.Gout[col * M + row] : 0.0;
+        a.WTp[i] = (in && row <= col) ? a.Gout[row * M + col] : 0.0;
+    }
     for (int i = tid; i < NBLK * DK * 64; i += PREP_NT) {
         const int l = i & 63, s = (i >> 6) % DK, rb = (i >> 6) / DK;
         const int row = 16 * rb + (l & 15), col = 4 * s + (l >> 4);
         a.Zp[i] = (row < M && col < D) ? a.Zs[row * D + col] : 0.0;
     }
+    // infinity-norm condition number of K_mm + jitter I (row sums of |K| and |K^-1|): what the caller's choice between
+    // the dense and the two-triangular GP form goes by
+    double kn = 0.0, kin = 0.0;
+    for (int i = wv; i < M; i += NWAVE) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = l; k < M; k += 64) {
+            s1 += fabs(a.Kmm[i * M + k]) + (k == i ? a.jitter : 0.0);
+            s2 += fabs(Cm[i * M + k]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        kn = fmax(kn, s1);
+        kin = fmax(kin, s2);
+    }
+    __shared__ double cn[2][PREP_NT / 64];
+    if (l == 0) { cn[0][wv] = kn; cn[1][wv] = kin; }
     const double logvar = log(var);
     for (int m = tid; m < Mp; m += PREP_NT) a.cz[m] = (m < M) ? (-0.5 * Xs[m] + logvar) : -1e30;
     for (int i = tid; i < NBLK * 4 * 64; i += PREP_NT) {
@@ -365,9 +392,12 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
         a.scal[CBFSSM_SCAL_KLZ] = 0.5 * (tot + double(Do) * (logdet - double(M)));
         a.scal[CBFSSM_SCAL_INFO] = double(s_info);
         for (int i = 4; i < CBFSSM_SCAL_COUNT; ++i) a.scal[i] = 0.0;
+        double c0 = 0.0, c1 = 0.0;
+        for (int i = 0; i < NWAVE; ++i) { c0 = fmax(c0, cn[0][i]); c1 = fmax(c1, cn[1][i]); }
+        a.scal[CBFSSM_SCAL_COND] = c0 * c1;
 #ifdef CBF_PREP_STAMPS
-        a.scal[4] = double(tk_pan); a.scal[5] = double(tk_upd); a.scal[6] = double(tk2 - tk1); a.scal[7] = double(clock64() - tk2);
-        // (scal[4..7]: cycles in panels, rank updates, outputs + K^-1 = G G^T, operand images + KL; Kmm build = rest)
+        a.scal[8] = double(tk_pan); a.scal[9] = double(tk_upd); a.scal[10] = double(tk2 - tk1); a.scal[11] = double(clock64() - tk2);
+        // (scal[8..11]: cycles in panels, rank updates, outputs + K^-1 = G G^T, operand images + KL; Kmm build = rest)
 #endif
     }
 }
@@ -580,6 +610,7 @@ static PackPtrs pack_ptrs(const cbfssm_pack_layout* L, const double* pack)
     p.Bp = pack + L->Bp; p.Zp = pack + L->Zp; p.cz = pack + L->cz; p.muA = pack + L->muA; p.s2A = pack + L->s2A;
     p.invl = pack + L->invl; p.scal = pack + L->scal;
     p.KSr = (L->M + 3) / 4;
+    p.Wp = pack + L->Wp; p.WTp = pack + L->WTp;
     return p;
 }
 
@@ -700,6 +731,9 @@ int cbfssm_gp_pack_layout(int M, int D, int Do, cbfssm_pack_layout* out)
     out->rev_slab = rev_slab(nblk, dk);
     out->rev_stash = (nblk > 7) ? 1 : 0;
     out->work = take(M > PREP_LDS_MAX_M ? int64_t(M) * (M | 1) : 0);
+    out->Wp = take(int64_t(nblk) * out->KS * 64);
+    out->WTp = take(int64_t(nblk) * out->KS * 64);
+    out->gp_form = CBFSSM_GP_FORM_DENSE;
     out->total = o;
     return 0;
 }
@@ -731,6 +765,7 @@ static int fill_prep(PrepArgs& a, const cbfssm_pack_layout* L, const double* Z, 
     a.Bp = pack + L->Bp; a.Zp = pack + L->Zp; a.cz = pack + L->cz; a.muA = pack + L->muA; a.s2A = pack + L->s2A;
     a.invl = pack + L->invl; a.scal = pack + L->scal;
     a.muB = pack + L->muB; a.s2B = pack + L->s2B; a.ZT = pack + L->ZT; a.JB = L->JB;
+    a.Wp = pack + L->Wp; a.WTp = pack + L->WTp;
     return 0;
 }
 
@@ -767,6 +802,7 @@ int cbfssm_gp_predict_f64(const cbfssm_pack_layout* L, const double* pack, const
     if (npts == 0) return 0;
     PredictArgs a;
     a.pk = pack_ptrs(L, pack); a.X = X; a.npts = npts; a.D = L->D; a.Do = L->Do; a.fmean = fmean; a.fvar = fvar;
+    a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
     int rc = dispatch_predict(L->NBLK, L->DK, a, (hipStream_t)stream);
     if (rc) return fail(rc, "gp_predict launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
@@ -804,7 +840,8 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
     int n0, n1;
     bwd_segments(p, &n0, &n1);
     a.nseg0 = n0;
-    const int nc = pass_nc(p, MODE_BWD);
+    a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
+    const int nc = a.tri ? 1 : pass_nc(p, MODE_BWD);
     int g0, ng, gt;
     rc = group_range(p, nc, &g0, &ng, &gt);
     if (rc) return rc;
@@ -851,7 +888,8 @@ static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.half = p->half; a.x0 = x0;
     a.fmv = fmv_f;
     a.a2s = a2s_f;
-    const int nc = pass_nc(p, MODE_FWD);
+    a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
+    const int nc = a.tri ? 1 : pass_nc(p, MODE_FWD);
     int g0, ng, gt;
     rc = group_range(p, nc, &g0, &ng, &gt);
     if (rc) return rc;

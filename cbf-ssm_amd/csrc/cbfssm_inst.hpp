@@ -31,13 +31,22 @@ template <int NBLK, int DK>
 int launch_predict_t(const PredictArgs& a, hipStream_t st)
 {
     typedef Cfg<NBLK> C;
-    typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
-    const size_t lds = TT::LDS_DOUBLES * sizeof(double);
-    auto k = predict_kernel<NBLK, C::RB, DK, C::BREG>;
-    int rc = set_lds(k, lds);
-    if (rc) return rc;
     const unsigned groups = unsigned((a.npts + 15) / 16);
-    hipLaunchKernelGGL(k, dim3(groups), dim3(TT::NT), lds, st, a);
+    if (a.tri) {
+        typedef Tile<NBLK, C::RB, DK, C::BREG, true> TT;
+        const size_t lds = TT::LDS_DOUBLES * sizeof(double);
+        auto k = predict_kernel<NBLK, C::RB, DK, C::BREG, true>;
+        int rc = set_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, dim3(groups), dim3(TT::NT), lds, st, a);
+    } else {
+        typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
+        const size_t lds = TT::LDS_DOUBLES * sizeof(double);
+        auto k = predict_kernel<NBLK, C::RB, DK, C::BREG>;
+        int rc = set_lds(k, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, dim3(groups), dim3(TT::NT), lds, st, a);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
 }
@@ -52,7 +61,15 @@ int launch_pass_t(const PassArgs& a, dim3 grid, int nc, hipStream_t st)
     const size_t lds = (size_t(nc == 1 ? 1 : 2) * (TT::LDS_DOUBLES - 64) + 64 + (nc == 1 ? TT::EPI_LDS_DOUBLES : 0)) *
                        sizeof(double);
     hipError_t e;
-    if (nc == 3) {
+    if (a.tri) {
+        // the reference's two-triangular form: one column block per workgroup (the caller passes nc = 1)
+        typedef Tile<NBLK, C::RB, DK, C::BREG, true> TR;
+        const size_t ldt = (size_t(TR::LDS_DOUBLES) + TR::EPI_LDS_DOUBLES) * sizeof(double);
+        auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 1, true>;
+        int rc = set_lds(k, ldt);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k, grid, dim3(TR::NT), ldt, st, a);
+    } else if (nc == 3) {
         auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 2>;
         int rc = set_lds(k, lds);
         if (rc) return rc;

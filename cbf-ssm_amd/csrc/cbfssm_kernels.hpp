@@ -230,7 +230,26 @@ struct PackPtrs {
     const double* invl;
     const double* scal;
     int KSr;
+    const double* Wp;    // two-triangular form: W = L^-1 as A-operand image [NBLK][KS][64] (zero above the diagonal)
+    const double* WTp;   //                      W^T as A-operand image [NBLK][KS][64] (zero below the diagonal)
 };
+
+// Workgroup-scope LDS flags of the two-triangular GP form: wave p publishes the rows of A = L^-1 k it owns and raises
+// flag[p] to the step's epoch; a consumer polls before it reads those rows.  Every wave raises its flag in every step
+// before it waits on anybody (no cycle), and the poll is bounded.
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ void flag_release(int* f, int v)
+{
+    __hip_atomic_store((lds_int*)f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void flag_wait(int* f, int v)
+{
+    int spins = 0;
+    while (__hip_atomic_load((lds_int*)f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) break;          // never reached in a correct launch; keeps a broken one from hanging
+    }
+}
 
 struct PassArgs {
     PackPtrs pk;
@@ -260,6 +279,7 @@ struct PassArgs {
                            // in MFMA C-layout (slot = t for fwd, run*T + t for bwd)
     double* fmv;           // optional: per-step (fmean, fvar) after residual / process noise, kept for the adjoint:
                            // fwd [(T-1)][N][dim_x][2], bwd [2][T][N][dim_x-dim_y][2]
+    int tri;               // 1: GP conditional in the reference's two-triangular form (gp_tf.py:137-145), 0: K^-1 contraction
 };
 
 struct PredictArgs {
@@ -269,16 +289,27 @@ struct PredictArgs {
     int D, Do;
     double* fmean;     // (npts, Do)
     double* fvar;
+    int tri;
 };
 
-template <int NBLK, int RB, int DK, bool BREG>
+// TRI: the GP conditional in the reference's own two-triangular form (gp_tf.py:137-145) instead of the K^-1 contraction:
+//   A = W K (W = L^-1, lower triangular), fvar_0 = sigma^2 - colsum(A o A), A2 = W^T A (upper triangular)
+// -- the same M^2 multiply-adds per point when the zero blocks are skipped, and sigma^2 - |L^-1 k|^2 does not cancel the
+// way sigma^2 - k.(K^-1 k) does on an ill-conditioned K_mm.  Row block rb of A needs the k-blocks 0..rb, row block rb of
+// A2 the blocks rb..NBLK-1 of A: NBLK + 1 blocks per row block in total, whoever owns it.  The A rows travel through
+// an LDS tile; a consumer waits for the producing wave's flag, not for a workgroup barrier, so wave rb starts its second
+// product when its own rows are done and meets the rows of the later blocks as they appear.
+template <int NBLK, int RB, int DK, bool BREG, bool TRI = false>
 struct Tile {
     static constexpr int W = (NBLK + RB - 1) / RB;   // waves per workgroup
     static constexpr int NT = 64 * W;
     static constexpr int MP = 16 * NBLK;
     static constexpr int KS = MP / 4;                // k-steps of the K^-1 K product
     static constexpr int QPW = (4 + W - 1) / W;      // state-row groups (4 rows each) per wave in phase 3
-    static constexpr int LDS_DOUBLES = DK * 64 + MP * 16 + W * 512 + 64;   // per column block (+64 once)
+    static constexpr int TRI_LDS = TRI ? MP * 16 + 64 : 0;                 // A = L^-1 k tile + the waves' flags
+    static constexpr int LDS_DOUBLES = DK * 64 + MP * 16 + W * 512 + 64 + TRI_LDS;   // per column block (+64 once)
+    static constexpr int NBR = BREG ? (TRI ? KS + 4 : KS) : 1;            // loop-invariant matrix operands in VGPRs
+    static_assert(!(TRI && BREG) || RB == 1, "register-resident triangular operands: one row block per wave");
     // pass_kernel<NC = 1>, streamed K^-1: how many of the mean / variance operand images fit into LDS next to the tiles
     static constexpr int EPI_LDS_N = BREG ? 0 : (LDS_DOUBLES + 2 * NBLK * 256 <= 20480 ? 2 : (LDS_DOUBLES + NBLK * 256 <= 20480 ? 1 : 0));
     static constexpr bool EPI_LDS = EPI_LDS_N > 0;
@@ -289,8 +320,10 @@ struct Tile {
     double czr[RB][4];
     double muA[RB][4];
     double s2A[RB][4];
-    double Breg[BREG ? RB : 1][BREG ? KS : 1];
+    double Breg[BREG ? RB : 1][NBR];
     const double* Bp;
+    const double* Wp;
+    const double* WTp;
     const double* muAg;
     const double* s2Ag;
     int lane_;
@@ -301,6 +334,8 @@ struct Tile {
     __device__ __forceinline__ void load_operands(const PackPtrs& pk, int w, int l)
     {
         Bp = pk.Bp;
+        Wp = pk.Wp;
+        WTp = pk.WTp;
         muAg = pk.muA;
         s2Ag = pk.s2A;
         lane_ = l;
@@ -321,11 +356,201 @@ struct Tile {
                     s2A[i][r] = ok ? pk.s2A[(rbc * 4 + r) * 64 + l] : 0.0;
                 }
             }
-            if (BREG) {
+            if constexpr (BREG && !TRI) {
 #pragma unroll
                 for (int s = 0; s < KS; ++s) Breg[i][s] = ok ? pk.Bp[(rbc * KS + s) * 64 + l] : 0.0;
             }
         }
+        if constexpr (BREG && TRI) load_tri_dispatch<0>(pk, __builtin_amdgcn_readfirstlane(w), l);
+    }
+
+    // register-resident triangular operands of the wave that owns row block RBI: 4 (RBI + 1) k-steps of W's row block
+    // (blocks 0..RBI), then KS - 4 RBI k-steps of W^T's row block (blocks RBI..NBLK-1): KS + 4 in total for every wave.
+    // The indices must be compile-time constants (a register array), hence one instantiation per row block.
+    template <int RBI>
+    __device__ __forceinline__ void load_tri_reg(const PackPtrs& pk, int l)
+    {
+        constexpr int N1 = 4 * (RBI + 1);
+#pragma unroll
+        for (int s = 0; s < N1; ++s) Breg[0][s] = pk.Wp[(RBI * KS + s) * 64 + l];
+#pragma unroll
+        for (int j = 0; j < KS - 4 * RBI; ++j) Breg[0][N1 + j] = pk.WTp[(RBI * KS + 4 * RBI + j) * 64 + l];
+    }
+    template <int I>
+    __device__ __forceinline__ void load_tri_dispatch(const PackPtrs& pk, int wu, int l)
+    {
+        if constexpr (I < NBLK) {
+            if (wu == I) load_tri_reg<I>(pk, l);
+            else load_tri_dispatch<I + 1>(pk, wu, l);
+        }
+    }
+
+    // ---- phase 2 in the two-triangular form.  epilogue shared by both operand sources: a2 rows -> P1/P2 partials
+    __device__ __forceinline__ void tri_epilogue(const d4 (&a2)[RB], double q, double* part, int w, int l, double* a2o)
+    {
+        d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int rb = w * RB + i;
+            if (rb < NBLK) {
+                if (a2o) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a2o[rb * 256 + r * 64 + l] = a2[i][r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double mu_op = BREG ? muA[i][r] : muAg[(rb * 4 + r) * 64 + lane_];
+                    const double s2_op = BREG ? s2A[i][r] : s2Ag[(rb * 4 + r) * 64 + lane_];
+                    P1 = CBF_MFMA(mu_op, a2[i][r], P1);
+                    P2 = CBF_MFMA(s2_op, a2[i][r] * a2[i][r], P2);
+                }
+            }
+        }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            part[((w * 2 + 0) * 4 + r) * 64 + l] = P1[r];
+            part[((w * 2 + 1) * 4 + r) * 64 + l] = P2[r] - q;       // fvar_0 - sigma^2 = -colsum(A o A)   (gp_tf.py:140)
+        }
+    }
+
+    // operands in VGPRs (NBLK <= 7, one row block per wave); RBI = the wave's row block
+    template <int RBI>
+    __device__ __forceinline__ void phase2_tri_reg(const double* Kt, double* At, int* flag, int epoch, double* part, int l,
+                                                   double* a2o)
+    {
+        constexpr int N1 = 4 * (RBI + 1);
+        // A rows of this block: W[RBI, 0..RBI] K[0..RBI]                                         (gp_tf.py:137)
+        d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < N1; ++s) {
+            if (s < KSr) {
+                const double b = Kt[64 * s + l];
+                if (s & 1) acc1 = CBF_MFMA(Breg[0][s], b, acc1);
+                else acc0 = CBF_MFMA(Breg[0][s], b, acc0);
+            }
+        }
+        const d4 A = acc0 + acc1;
+        double q = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            At[256 * RBI + 64 * r + l] = A[r];
+            q = fma(A[r], A[r], q);
+        }
+        flag_release(flag + RBI, epoch);
+        // A2 rows of this block: W^T[RBI, RBI..] A[RBI..]                                        (gp_tf.py:145)
+        // (the accumulator of this wave's own A rows is already the B operand of their k-steps: C layout = B layout)
+        d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (4 * RBI + r < KSr) {
+                if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + r], A[r], c1);
+                else c0 = CBF_MFMA(Breg[0][N1 + r], A[r], c0);
+            }
+        }
+#pragma unroll
+        for (int kb = RBI + 1; kb < NBLK; ++kb) {
+            if (4 * kb < KSr) {
+                flag_wait(flag + kb, epoch);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int s = 4 * kb + r;
+                    if (s < KSr) {
+                        const double b = At[64 * s + l];
+                        if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c1);
+                        else c0 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c0);
+                    }
+                }
+            }
+        }
+        d4 a2[RB];
+        a2[0] = c0 + c1;
+        tri_epilogue(a2, q, part, RBI, l, a2o);
+    }
+    template <int I>
+    __device__ __forceinline__ void phase2_tri_dispatch(const double* Kt, double* At, int* flag, int epoch, double* part,
+                                                        int wu, int l, double* a2o)
+    {
+        if constexpr (I < NBLK) {
+            if (wu == I) phase2_tri_reg<I>(Kt, At, flag, epoch, part, l, a2o);
+            else phase2_tri_dispatch<I + 1>(Kt, At, flag, epoch, part, wu, l, a2o);
+        }
+    }
+
+    // operands streamed from L2 (NBLK >= 10): W and W^T as lane-linear A-operand images, zero blocks skipped
+    __device__ __forceinline__ void phase2_tri_stream(const double* Kt, double* At, int* flag, int epoch, double* part,
+                                                      int w, int l, double* a2o)
+    {
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int rb = w * RB + i;
+            if (rb < NBLK) {
+                d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+                const int n1 = min(4 * (rb + 1), KSr);
+                const double* ap = Wp + (rb * KS) * 64 + l;
+#pragma unroll 1
+                for (int s0 = 0; s0 < n1; s0 += 4) {
+                    double b[4], aop[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        aop[j] = ap[(s0 + j) * 64];
+                        b[j] = Kt[64 * (s0 + j) + l];
+                    }
+                    acc0 = CBF_MFMA(aop[0], b[0], acc0);
+                    acc1 = CBF_MFMA(aop[1], b[1], acc1);
+                    acc0 = CBF_MFMA(aop[2], b[2], acc0);
+                    acc1 = CBF_MFMA(aop[3], b[3], acc1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double av = acc0[r] + acc1[r];
+                    At[256 * rb + 64 * r + l] = av;
+                    q = fma(av, av, q);
+                }
+            }
+        }
+        flag_release(flag + w, epoch);
+        d4 c[RB][2];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) { c[i][0] = d4{0, 0, 0, 0}; c[i][1] = d4{0, 0, 0, 0}; }
+        const int kbe = (KSr + 3) >> 2;                       // k-blocks that carry data
+#pragma unroll 1
+        for (int kb = w * RB; kb < kbe; ++kb) {
+            // W^T operands of this k-block first: they do not depend on the producer's flag
+            double aop[RB][4];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int rb = min(w * RB + i, NBLK - 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) aop[i][j] = WTp[(rb * KS + 4 * kb + j) * 64 + l];
+            }
+            const int pw = kb / RB;
+            if (pw != w) flag_wait(flag + pw, epoch);
+            double b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = At[64 * (4 * kb + j) + l];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int rb = w * RB + i;
+                if (rb < NBLK && rb <= kb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c[i][j & 1] = CBF_MFMA(aop[i][j], b[j], c[i][j & 1]);
+                }
+            }
+        }
+        d4 a2[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) a2[i] = c[i][0] + c[i][1];
+        tri_epilogue(a2, q, part, w, l, a2o);
+    }
+
+    __device__ __forceinline__ void phase2_tri(const double* Kt, double* At, int* flag, int epoch, double* part, int w, int l,
+                                               double* a2o = nullptr)
+    {
+        if constexpr (BREG) phase2_tri_dispatch<0>(Kt, At, flag, epoch, part, __builtin_amdgcn_readfirstlane(w), l, a2o);
+        else phase2_tri_stream(Kt, At, flag, epoch, part, w, l, a2o);
     }
 
     // phases 1 and 2 for NC column blocks of 16 points whose scaled inputs sit in xq[c]; leaves the P1/P2 partials
@@ -602,14 +827,16 @@ struct LogProd {
 // ---------------------------------------------------------------------------------------------------------------------
 // GPModel.predict for arbitrary points (gp_tf.py:132-161)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBLK, int RB, int DK, bool BREG>
+template <int NBLK, int RB, int DK, bool BREG, bool TRI = false>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(PredictArgs a)
 {
-    typedef Tile<NBLK, RB, DK, BREG> TT;
+    typedef Tile<NBLK, RB, DK, BREG, TRI> TT;
     extern __shared__ double lds[];
     double* xq = lds;
     double* Kt = xq + DK * 64;
     double* part = Kt + TT::MP * 16;
+    double* At = part + TT::W * 512 + 64;            // TRI: A = L^-1 k tile, then the waves' flags
+    int* flag = reinterpret_cast<int*>(At + TT::MP * 16);
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     TT tile;
     tile.load_operands(a.pk, w, l);
@@ -621,8 +848,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(Pr
         if (j < a.D && p < a.npts) v = a.X[p * a.D + j] * a.pk.invl[j];
         xq[i] = v;
     }
+    if constexpr (TRI) {
+        if (tid < 64) flag[tid] = 0;
+    }
     __syncthreads();
-    tile.template gp_phases<1>(xq, Kt, part, w, l);
+    double kr[RB][4];
+    tile.phase1(xq, Kt, kr, w, l);
+    __syncthreads();
+    if constexpr (TRI) tile.phase2_tri(Kt, At, flag, 1, part, w, l);
+    else tile.phase2(Kt, part, kr, w, l);
     __syncthreads();
 #pragma unroll
     for (int qi = 0; qi < TT::QPW; ++qi) {
@@ -645,10 +879,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(Pr
 // MODE_BWD: one resample-to-resample segment of one CBFSSM._backward_body run (cbfssm.py:107-158).
 // NC: column blocks (16 chains each) per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBLK, int RB, int DK, bool BREG, int MODE, int NC>
+template <int NBLK, int RB, int DK, bool BREG, int MODE, int NC, bool TRI = false>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassArgs a)
 {
-    typedef Tile<NBLK, RB, DK, BREG> TT;
+    static_assert(!TRI || NC == 1, "the two-triangular form runs one column block per workgroup");
+    typedef Tile<NBLK, RB, DK, BREG, TRI> TT;
     constexpr int W = TT::W, NT = TT::NT;
     constexpr int NTASK = 4 * NC;                    // (state-row group q, column block) pairs of phase 3
     constexpr int QPW = (NTASK + W - 1) / W;
@@ -659,6 +894,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     double* Kt = xq + NC * XS;                       // [NC][MP*16]
     double* part = Kt + NC * KTS;                    // [NC][W][512]
     double* red = part + NC * PS;
+    double* At = red + 64 + ((TT::EPI_LDS && NC == 1) ? TT::EPI_LDS_DOUBLES : 0);   // TRI: A = L^-1 k tile, then the flags
+    int* flag = reinterpret_cast<int*>(At + TT::MP * 16);
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do;
@@ -758,6 +995,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     // ---- initial state and first input
     // xq rows [0,Do) carry the chain state, rows [Do,D) the auxiliary inputs, rows [D,4*DK) stay zero
     for (int i = tid; i < NC * XS; i += NT) xq[i] = 0.0;
+    if constexpr (TRI) {
+        if (tid < 64) flag[tid] = 0;
+    }
     __syncthreads();
     const bool resample0 = (MODE == MODE_BWD) && (((t_first + 1 + run * R) % P) == 0);
     const int tm0 = (MODE == MODE_BWD) ? (t_first % P) : 0;
@@ -837,7 +1077,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
             double kr[RB][4];
             tile.phase1(xq, Kt, kr, w, l);
             CBF_STAMP_BARRIER(1);
-            tile.phase2(Kt, part, kr, w, l, a2o);
+            if constexpr (TRI) tile.phase2_tri(Kt, At, flag, step + 1, part, w, l, a2o);
+            else tile.phase2(Kt, part, kr, w, l, a2o);
         } else {
             tile.template gp_phases<NC>(xq, Kt, part, w, l, a2o, G16 - gx * NC);
         }

@@ -34,7 +34,16 @@ enum {
     CBFSSM_SCAL_LOGDET = 1,  /* log det (K_mm + jitter I) */
     CBFSSM_SCAL_KLZ = 2,     /* prior_kl() */
     CBFSSM_SCAL_INFO = 3,    /* 0 = OK, k>0 = leading minor k not positive definite */
-    CBFSSM_SCAL_COUNT = 8
+    CBFSSM_SCAL_COND = 4,    /* infinity-norm condition number of K_mm + jitter I: |K|_inf |K^-1|_inf */
+    CBFSSM_SCAL_COUNT = 16
+};
+
+/* how GPModel.predict is evaluated by the pass / predict kernels (cbfssm_pack_layout.gp_form) */
+enum {
+    CBFSSM_GP_FORM_DENSE = 0,   /* A2 = K^-1 k as one dense product, fvar_0 = sigma^2 - k.A2                      */
+    CBFSSM_GP_FORM_TRI = 1      /* the reference's own order (gp_tf.py:137-145): A = L^-1 k, fvar_0 = sigma^2 - |A|^2,
+                                   A2 = L^-T A, as two triangular products -- same multiply-adds, no cancellation
+                                   of k.(K^-1 k) against sigma^2 on an ill-conditioned K_mm                        */
 };
 
 /* Offsets (in doubles) of the sections of one GP pack; filled by cbfssm_gp_pack_layout (host struct). */
@@ -57,7 +66,12 @@ typedef struct {
     int64_t ZT;       /* [NBLK][JB][4][64] (Z/lengthscale)^T as A-operand image A[row j][k = m]; row D = ones        */
     int64_t rev_slab; /* doubles of one adjoint partial slab (0: no adjoint kernel for this tile height)            */
     int64_t work;     /* [M][M|1]        factorisation workspace when M is too large for LDS                        */
+    int64_t Wp;       /* [NBLK][KS][64]  W = L^-1 (lower triangular) as MFMA A-operand image      (gp_tf.py:137)         */
+    int64_t WTp;      /* [NBLK][KS][64]  W^T = L^-T as MFMA A-operand image                        (gp_tf.py:145)         */
     int32_t M, D, Do, NBLK, DK, Mp, Dp, KS, JB, rev_stash;   /* rev_stash: 1 = adjoint runs in stash mode (M > 112) */
+    int32_t gp_form;  /* CBFSSM_GP_FORM_*: set by the caller after cbfssm_gp_pack_layout (which fills in DENSE); read by
+                         cbfssm_gp_predict_f64 and the pass kernels.  Both forms read the same pack.               */
+    int32_t reserved;
 } cbfssm_pack_layout;
 
 /* Problem description shared by the pass kernels (host struct, passed by pointer). */
