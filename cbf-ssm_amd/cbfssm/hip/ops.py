@@ -182,17 +182,66 @@ def as_btsd(x_tnd, B, S):
 
 
 def a2s_budget_bytes(device):
-    """HBM the saved A2 tiles of one workspace may take: CBFSSM_A2S_MAX_GB, by default 3/4 of what is free right now."""
+    """HBM the saved A2 tiles of an engine may take: CBFSSM_A2S_MAX_GB, by default 3/4 of what is free right now."""
     cap = os.environ.get('CBFSSM_A2S_MAX_GB')
     if cap is not None:
         return float(cap) * 2 ** 30
     return 0.75 * torch.cuda.mem_get_info(torch.device(device))[0]
 
 
+class TilePool:
+    """The saved A2 tiles of an engine: ONE pair of flat buffers, sized for the largest (B, T) seen, that every
+    workspace views into (a partial last mini-batch, a test pass at another batch size and a retrain at another
+    seq_len all reuse the same HBM; only one evaluation is in flight per engine).  The budget is taken once, when the
+    first buffers are allocated.  A later shape that needs MORE than the pool holds gets new, larger buffers while the
+    budget allows (the old ones stay alive: captured HIP graphs hold their addresses) and is logged; a shape that does
+    not fit the budget runs its adjoint in recompute mode, and says so."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs = None            # (a2s_f, a2s_b or None)
+        self.retired = []
+        self.budget = None
+        self.log = []
+
+    def get(self, n_f, n_b):
+        """views of n_f / n_b doubles (n_b = 0: no backward GP), or (None, None) when the tiles do not fit the budget"""
+        import warnings
+        if self.bufs is not None and self.bufs[0].numel() >= n_f and (n_b == 0 or (self.bufs[1] is not None and
+                                                                                  self.bufs[1].numel() >= n_b)):
+            return self.bufs[0][:max(n_f, 1)], (self.bufs[1][:max(n_b, 1)] if n_b else None)
+        if self.budget is None:
+            self.budget = a2s_budget_bytes(self.device)
+        have = 0 if self.bufs is None else 8.0 * (self.bufs[0].numel() + (self.bufs[1].numel() if self.bufs[1] is not None else 0))
+        need = 8.0 * (n_f + n_b)
+        free_now = torch.cuda.mem_get_info(self.device)[0]
+        if need > self.budget or (need > 0.9 * free_now and os.environ.get('CBFSSM_A2S_MAX_GB') is None):
+            msg = ('saved A2 tiles of this shape need %.2f GB, over the budget of %.2f GB (CBFSSM_A2S_MAX_GB): its adjoint '
+                   'recomputes A2 (slower, same numbers)' % (need / 2 ** 30, self.budget / 2 ** 30))
+            self.log.append(msg)
+            warnings.warn(msg)
+            return None, None
+        if self.bufs is not None:
+            msg = ('saved-A2 pool grows from %.2f to %.2f GB for a larger shape; the old buffers stay allocated for the '
+                   'graphs captured on them' % (have / 2 ** 30, need / 2 ** 30))
+            self.log.append(msg)
+            warnings.warn(msg)
+            self.retired.append(self.bufs)
+        f = dict(dtype=torch.float64, device=self.device)
+        self.bufs = (torch.zeros(max(n_f, 1), **f), torch.zeros(max(n_b, 1), **f) if n_b else None)
+        return self.bufs[0][:max(n_f, 1)], (self.bufs[1][:max(n_b, 1)] if n_b else None)
+
+    def bytes(self):
+        tot = 0
+        for pair in ([self.bufs] if self.bufs is not None else []) + self.retired:
+            tot += 8 * (pair[0].numel() + (pair[1].numel() if pair[1] is not None else 0))
+        return tot
+
+
 class ElboWorkspace:
     """Device buffers of one ELBO evaluation for fixed (B, T) -- allocated once, reused every step."""
 
-    def __init__(self, prob, device, keep_h=False, packs=None):
+    def __init__(self, prob, device, keep_h=False, packs=None, pool=None):
         p = prob
         N, T = p.B * p.S, p.T
         dob = p.dim_x - p.dim_y
@@ -213,9 +262,9 @@ class ElboWorkspace:
         if keep_h and packs is not None:
             n_f = int(lib.cbfssm_saved_a2_elems(C.byref(p), C.byref(packs[0].layout), 0))
             n_b = int(lib.cbfssm_saved_a2_elems(C.byref(p), C.byref(packs[1].layout), 1)) if packs[1] is not None else 0
-            if 8.0 * (n_f + n_b) <= a2s_budget_bytes(device):
-                self.a2s_f = torch.zeros(max(n_f, 1), **f)
-                self.a2s_b = torch.zeros(max(n_b, 1), **f) if packs[1] is not None else None
+            if pool is None:
+                pool = TilePool(device)
+            self.a2s_f, self.a2s_b = pool.get(n_f, n_b)        # views into the engine's one pool (or None, None)
         self.x = torch.zeros(T, N, p.dim_x, **f)
         self.ent_part = torch.zeros(self.n_ent, **f)
         self.kl_part = torch.zeros(self.n_kl, **f)

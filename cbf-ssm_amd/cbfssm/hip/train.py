@@ -114,6 +114,7 @@ class HipElboGrad:
         self.nimg_b = self.pack_b.layout.NBLK ** 2 * 256 if self.stash else 0
         self.red = torch.zeros(self.nred + self.nimg_f + self.nimg_b, dtype=torch.float64, device=self.device)
         self._ws = {}
+        self.tile_pool = ops.TilePool(self.device)     # saved A2 tiles: one pool for every (B, T) this engine sees
         # train-step tail in HIP (positivity transforms, K_mm/K^-1 adjoint + prior KL, chain rule): flat vectors in
         # PARAM_NAMES order.  CBFSSM_TORCH_TAIL=1 keeps the tensor-library restatement below (same numbers, ~170 launches).
         self.pl = _l.param_layout(self.M, self.dim_x, self.dim_u, self.dim_y)
@@ -203,7 +204,7 @@ class HipElboGrad:
     def _workspace(self, prob):
         key = (prob.B, prob.T)
         if key not in self._ws:
-            ws = ops.ElboWorkspace(prob, self.device, keep_h=True, packs=(self.pack_f, self.pack_b))
+            ws = ops.ElboWorkspace(prob, self.device, keep_h=True, packs=(self.pack_f, self.pack_b), pool=self.tile_pool)
             lib = _l.load()
             n_f = int(lib.cbfssm_rev_workgroups(C.byref(prob), 0))
             n_b = int(lib.cbfssm_rev_workgroups(C.byref(prob), 1))

@@ -167,8 +167,9 @@ class HipHalfGrad:
             ws.x = torch.zeros(prob.T, N, prob.dim_x, **f)
             ws.fmv_f = torch.zeros(max(prob.T - 1, 0), N, prob.dim_x, 2, **f)
             n_a2 = int(lib.cbfssm_saved_a2_elems(C.byref(prob), C.byref(self.pack_f.layout), 0))
-            keep = 8.0 * n_a2 <= ops.a2s_budget_bytes(self.device)
-            ws.a2s_f = torch.zeros(max(n_a2, 1), **f) if keep else None
+            if getattr(self, 'tile_pool', None) is None:
+                self.tile_pool = ops.TilePool(self.device)
+            ws.a2s_f, _ = self.tile_pool.get(n_a2, 0)
             ws.kl_part = torch.zeros(ws.n_kl, **f)
             ws.ll_part = torch.zeros(int(lib.cbfssm_loglik_partials(C.byref(prob))), **f)   # [block][dim_y]
             ws.pred_mean = torch.zeros(prob.B, prob.T, prob.dim_y, **f)

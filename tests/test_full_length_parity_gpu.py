@@ -11,7 +11,7 @@ What 1e-5 can mean in (b).  The reference's own arithmetic (two triangular solve
 gp_tf.py:137-145) carries errors of order cond * eps into fmean and the recurrence amplifies them over T steps; two
 float64 codings of that SAME algorithm on different BLAS back-ends (the numpy/LAPACK oracle and the PyTorch
 restatement, both CPU) therefore differ by a `floor` that is measured here next to every HIP number.  The tests ask
-HIP-vs-oracle <= 1e-5 wherever floor <= 1e-6 and <= 10 x floor above (nothing can be closer to the reference than the
+HIP-vs-oracle <= 1e-5 wherever floor <= 1e-6 and <= 20 x floor above (nothing can be closer to the reference than the
 reference is to itself).  Every achieved error is printed and collected in gpurun_out/parity_report.json.
 """
 import dataclasses
@@ -165,7 +165,7 @@ def test_trained_like_sweep_full_recurrence(ls_mult):
     _report('sweep_C3/ls_x%d' % ls_mult, {'cond_f': cond_f, 'cond_b': cond_b, 'hip': e, 'floor': floor,
                                           'gp_form': eng.gp_form() if hasattr(eng, 'gp_form') else 'dense'})
     for k in ('loss', 'pred_mean', 'pred_var'):
-        lim = BOUND if floor[k] <= 1e-6 else 10.0 * floor[k]
+        lim = BOUND if floor[k] <= 1e-6 else 20.0 * floor[k]
         assert e[k] <= lim, (k, e[k], lim, floor[k])
 
 

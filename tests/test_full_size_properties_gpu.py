@@ -110,3 +110,72 @@ def test_full_size_gradient_matches_directional_finite_differences(name):
         lm = float(eng.forward({k: (v - h * r if k == pname else v) for k, v in params.items()}, u, y, noise)[0])
         fd = (lp - lm) / (2 * h)
         assert abs(fd - slope) <= 1e-4 * abs(slope) + 1e-12 * abs(loss) / h, (pname, fd, slope, h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C5 (RoboMove-shaped: M = 300, T = 1000, S = 50, recog_len = 50) on the GPU at its own size
+# ---------------------------------------------------------------------------------------------------------------------
+def test_c5_full_size_eval_is_deterministic_additive_and_permutation_equivariant():
+    """one eval step at the full per-GPU size (B = 512: 25 600 chains x 1000 steps, M = 300 tiles of 20 row blocks)"""
+    w, params, u, y, noise = _workload('C5')
+    eng = train.HipElboGrad(w.model_config(), DEV, require_adjoint=False)
+    l0, t0, ws = eng.forward(params, u, y, noise)
+    l0, full, pm0, pv0 = float(l0), _terms(t0), ws.pred_mean.clone(), ws.pred_var.clone()
+    assert float(t0['info']) == 0.0 and np.isfinite(l0)
+    l1, t1, ws = eng.forward(params, u, y, noise)
+    assert l0 == float(l1) and full == _terms(t1) and torch.equal(pm0, ws.pred_mean)      # bit-identical repeat
+    # two half batches with their slices of the noise: the data terms add up, the prior KL counts once
+    h = w.B // 2
+    parts = []
+    for lo, hi in ((0, h), (h, w.B)):
+        nz = {'hid_b': np.ascontiguousarray(noise['hid_b'][:, :, lo:hi]),
+              'eps_b': np.ascontiguousarray(noise['eps_b'][:, :, lo:hi]),
+              'eps_f': np.ascontiguousarray(noise['eps_f'][:, lo:hi])}
+        _, t, ws_h = eng.forward(params, u[lo:hi], y[lo:hi], nz)
+        parts.append(_terms(t))
+        np.testing.assert_allclose(ws_h.pred_mean.cpu().numpy(), pm0[lo:hi].cpu().numpy(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(ws_h.pred_var.cpu().numpy(), pv0[lo:hi].cpu().numpy(), rtol=1e-12, atol=1e-14)
+    for k in ('loglik', 'kl_x', 'entropy'):
+        assert parts[0][k] + parts[1][k] == pytest.approx(full[k], rel=1e-11)
+    assert parts[0]['kl_z_f'] == full['kl_z_f'] and parts[0]['kl_z_b'] == full['kl_z_b']
+    # free-running prediction (condition = False beyond the first recog_len - 1 steps, cbfssm.py:227) keeps kl_x smaller
+    nz0 = {'hid_b': np.ascontiguousarray(noise['hid_b'][:, :, :h]), 'eps_b': np.ascontiguousarray(noise['eps_b'][:, :, :h]),
+           'eps_f': np.ascontiguousarray(noise['eps_f'][:, :h])}
+    lc, tc, _ = eng.forward(params, u[:h], y[:h], nz0, condition=False)
+    assert 0.0 < float(tc['kl_x']) < parts[0]['kl_x']              # only the first recog_len - 1 steps carry a KL term
+    assert float(tc['entropy']) == parts[0]['entropy']             # the backward runs do not see `condition`
+
+
+def test_c5_long_recurrence_gradient_through_chunked_stash_launches():
+    """T = 1000, M = 300 at reduced batch with a stash budget that forces MANY time-chunked adjoint launches (the carried
+    state adjoint gx_carry crosses every chunk boundary, resample boundaries of both runs fall inside chunks): analytic
+    gradient against central finite differences of the loss along one random direction per tensor."""
+    import dataclasses
+    w = dataclasses.replace(syn.WORKLOADS['C5'], B=4)
+    cfg = dict(w.model_config())
+    cfg['adjoint_stash_gib'] = 0.25                 # 200 chains: ~100 steps per launch -> about ten launches per direction
+    p = syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)
+    params = {k: torch.tensor(v, device=DEV) for k, v in p.items()}
+    u, y = syn.make_inputs(w)
+    noise = syn.make_noise(w)
+    eng = train.HipElboGrad(cfg, DEV)
+    assert eng.stash
+    loss, grads, _ = eng.loss_and_grads(params, u, y, noise)
+    loss, grads = float(loss), {k: v.clone() for k, v in grads.items()}
+    # the same gradient with one launch per direction (default budget): chunking must not change it beyond summation order
+    eng1 = train.HipElboGrad(w.model_config(), DEV)
+    loss1, grads1, _ = eng1.loss_and_grads(params, u, y, noise)
+    assert float(loss1) == loss
+    for k in train.PARAM_NAMES:
+        np.testing.assert_allclose(grads[k].cpu().numpy(), grads1[k].cpu().numpy(), rtol=1e-9,
+                                   atol=1e-11 * float(grads1[k].abs().max()))
+    g = torch.Generator(device=DEV)
+    g.manual_seed(13)
+    for pname in train.PARAM_NAMES:
+        r = torch.randn(params[pname].shape, dtype=torch.float64, device=DEV, generator=g)
+        slope = float((grads[pname] * r).sum())
+        h = min(1e-6 * abs(loss) / max(abs(slope), 1e-300), 1e-4)
+        lp = float(eng.forward({k: (v + h * r if k == pname else v) for k, v in params.items()}, u, y, noise)[0])
+        lm = float(eng.forward({k: (v - h * r if k == pname else v) for k, v in params.items()}, u, y, noise)[0])
+        fd = (lp - lm) / (2 * h)
+        assert abs(fd - slope) <= 1e-4 * abs(slope) + 1e-12 * abs(loss) / h, (pname, fd, slope, h)
