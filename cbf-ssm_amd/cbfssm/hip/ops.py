@@ -128,6 +128,29 @@ class GPPack:
     def Kinv(self):
         return self.section('Kinv', (self.M, self.M))
 
+    def pack_f32(self):
+        """float32 MFMA images of this pack for the float32-arithmetic passes (cbfssm_gp_pack_f32): the Cholesky and K^-1
+        were computed in float64 and are cast here, as the reference does for float32 models (gp_tf.py:57-65)."""
+        lib = _l.load()
+        if getattr(self, 'buf32', None) is None:
+            n = int(lib.cbfssm_pack_f32_elems(C.byref(self.layout)))
+            self.buf32 = torch.zeros(n, dtype=torch.float32, device=self.buf.device)
+        _l.check(lib.cbfssm_gp_pack_f32(C.byref(self.layout), _ptr(self.buf), C.c_void_p(self.buf32.data_ptr()), _stream()),
+                 'cbfssm_gp_pack_f32')
+        return self.buf32
+
+    def predict_f32(self, X):
+        X = _f64(X, self.buf.device)
+        assert X.dim() == 2 and X.shape[1] == self.D
+        n = X.shape[0]
+        fmean = torch.empty(n, self.Do, dtype=torch.float64, device=X.device)
+        fvar = torch.empty_like(fmean)
+        b32 = self.pack_f32()
+        rc = _l.load().cbfssm_gp_predict_f32(C.byref(self.layout), C.c_void_p(b32.data_ptr()), _ptr(X), n, _ptr(fmean),
+                                             _ptr(fvar), _stream())
+        _l.check(rc, 'cbfssm_gp_predict_f32')
+        return fmean, fvar
+
     def predict(self, X):
         X = _f64(X, self.buf.device)
         assert X.dim() == 2 and X.shape[1] == self.D
@@ -277,7 +300,7 @@ class ElboWorkspace:
 
 
 def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, loss_factors, ws=None,
-                 keep_h=False):
+                 keep_h=False, f32=False):
     """One forward evaluation of the ELBO (cbfssm.py:84-271) from prepared GP packs.  Asynchronous.
 
     Returns the workspace; ws.out = [loglik, kl_x, entropy, kl_z_f, kl_z_b, elbo, loss, info].
@@ -292,6 +315,17 @@ def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, 
     assert u.shape == (prob.B, prob.T, prob.dim_u) and y.shape == (prob.B, prob.T, prob.dim_y)
     assert hid_b.numel() == 2 * prob.T * N and eps_b.numel() == 2 * prob.T * N
     assert eps_f.numel() == (prob.T - 1) * N
+    if f32:
+        # float32 arithmetic in the time loops (cbfssm_*_pass_f32), float64 storage; forward evaluation only
+        b32, f32p = pack_b.pack_f32(), pack_f.pack_f32()
+        rc = lib.cbfssm_backward_pass_f32(pb, C.byref(pack_b.layout), C.c_void_p(b32.data_ptr()), _ptr(var_x), _ptr(u),
+                                          _ptr(y), _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.ent_part), st)
+        _l.check(rc, 'cbfssm_backward_pass_f32')
+        rc = lib.cbfssm_forward_pass_f32(pb, C.byref(pack_f.layout), C.c_void_p(f32p.data_ptr()), _ptr(var_x), _ptr(var_y),
+                                         _ptr(u), _ptr(y), _ptr(ws.y2), _ptr(eps_f) if eps_f.numel() else None,
+                                         _ptr(ws.x), _ptr(ws.kl_part), st)
+        _l.check(rc, 'cbfssm_forward_pass_f32')
+        return _elbo_tail(lib, pb, prob, pack_f, pack_b, var_y, y, loss_factors, ws, st)
     rc = lib.cbfssm_backward_pass_f64(pb, C.byref(pack_b.layout), _ptr(pack_b.buf), _ptr(var_x), _ptr(u), _ptr(y),
                                       _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.fmv_b),
                                       _ptr(ws.a2s_b), _ptr(ws.ent_part), st)
@@ -300,6 +334,10 @@ def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, 
                                      _ptr(u), _ptr(y), _ptr(ws.y2), _ptr(eps_f) if eps_f.numel() else None,
                                      _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st)
     _l.check(rc, 'cbfssm_forward_pass_f64')
+    return _elbo_tail(lib, pb, prob, pack_f, pack_b, var_y, y, loss_factors, ws, st)
+
+
+def _elbo_tail(lib, pb, prob, pack_f, pack_b, var_y, y, loss_factors, ws, st):
     rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(var_y), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part), _ptr(ws.pred_mean),
                                        _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)
     _l.check(rc, 'cbfssm_loglik_moments_f64')
@@ -319,13 +357,17 @@ def tf_forward(x):
 class HipElbo:
     """Forward-only ELBO evaluator on one device from the twelve unconstrained tensors (no autograd)."""
 
-    def __init__(self, config, device):
+    def __init__(self, config, device, dtype='float64'):
+        """dtype 'float32': the time loops compute in float32 (cbfssm_*_pass_f32; the reference's model dtype argument,
+        cbfssm.py:12, with the Cholesky kept in float64, gp_tf.py:57-65); storage and the ELBO reductions stay float64."""
         self.config = config
         self.device = torch.device(device)
+        assert dtype in ('float64', 'float32')
+        self.f32 = dtype == 'float32'
         self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
         self.M, self.S = config['ind_pnt_num'], config['samples']
         D = self.dim_x + self.dim_u
-        mode = gp_form_mode(config)
+        mode = gp_form_mode(config) if not self.f32 else 'dense'      # (the float32 passes use the contraction form)
         self.pack_f = GPPack(self.M, D, self.dim_x, self.device, mode)
         self.pack_b = GPPack(self.M, D, self.dim_x - self.dim_y, self.device, mode)
         self._ws = {}
@@ -358,7 +400,7 @@ class HipElbo:
         ws = self._ws[key]
         hid_b, eps_b, eps_f = (_f64(noise[k], self.device) for k in ('hid_b', 'eps_b', 'eps_f'))
         elbo_forward(prob, self.pack_f, self.pack_b, self.var_x, self.var_y, u, y, hid_b, eps_b, eps_f,
-                     self.config['loss_factors'], ws)
+                     self.config['loss_factors'], ws, f32=self.f32)
         return ws
 
 

@@ -85,15 +85,19 @@ class StashContract:
 class HipElboGrad:
     """loss and d loss / d (12 unconstrained tensors) for one mini-batch on one device."""
 
-    def __init__(self, config, device, dist=None, require_adjoint=True):
+    def __init__(self, config, device, dist=None, require_adjoint=True, dtype='float64'):
         self.config = config
         self.device = torch.device(device)
         self.dist = dist
+        # float32: the time loops of the FORWARD evaluation compute in float32 (cbfssm_*_pass_f32); there is no float32
+        # adjoint, so a float32 engine serves loss / prediction fetches only
+        assert dtype in ('float64', 'float32')
+        self.f32 = dtype == 'float32'
         self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
         self.M, self.S = config['ind_pnt_num'], config['samples']
         self.D = self.dim_x + self.dim_u
         self.dob = self.dim_x - self.dim_y
-        mode = ops.gp_form_mode(config)
+        mode = ops.gp_form_mode(config) if not self.f32 else 'dense'
         self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device, mode)
         self.pack_b = GPPack(self.M, self.D, self.dob, self.device, mode)
         self.has_adjoint = all(pk.layout.rev_slab > 0 for pk in (self.pack_f, self.pack_b))
@@ -131,6 +135,9 @@ class HipElboGrad:
         return tuple(pk.update_form() for pk in (self.pack_f, self.pack_b))
 
     def _need_adjoint(self):
+        if self.f32:
+            raise NotImplementedError('float32 models evaluate the ELBO and the predictions; the gradient path (model.train) '
+                                      'computes in float64 only')
         if not self.has_adjoint:
             raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d)' % (self.M, self.pack_f.layout.NBLK))
 
@@ -368,9 +375,10 @@ class HipElboGrad:
 
     def _elbo_forward(self, prob, ws, c, u, y, hid_b, eps_b, eps_f):
         lf = self.config['loss_factors']
-        split = self._split(prob, adjoint=False)
+        split = self._split(prob, adjoint=False) if not self.f32 else None
         if split is None:
-            ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws)
+            ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws,
+                             f32=self.f32)
             return
         lib = _l.load()
         main, rest = split

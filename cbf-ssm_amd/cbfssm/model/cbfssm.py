@@ -29,9 +29,17 @@ def backward(y):
 class CBFSSM(BaseModel):
 
     def __init__(self, config, dtype='float64'):
-        if str(dtype) not in ('float64', 'torch.float64', "<dtype: 'float64'>"):
-            raise NotImplementedError('the HIP path computes in float64 (the reference default, cbfssm.py:12)')
-        super(CBFSSM, self).__init__(config, dtype='float64')
+        """dtype: 'float64' (the reference default, cbfssm.py:12) or 'float32' (also accepted: torch / numpy / TensorFlow
+        dtype objects of those names).  A float32 model runs its time loops in float32 with the Cholesky kept in
+        float64 (gp_tf.py:57-65) and serves loss / prediction fetches; `model.train` needs float64."""
+        name = str(dtype)
+        if 'float64' in name or name in ('double', 'f64'):
+            dt = 'float64'
+        elif 'float32' in name or name in ('float', 'f32'):
+            dt = 'float32'
+        else:
+            raise NotImplementedError('dtype %r: the HIP path computes in float64 or float32' % (dtype,))
+        super(CBFSSM, self).__init__(config, dtype=dt)
 
     # ---- cbfssm.py:15-23
     def _build_graph(self):
@@ -107,7 +115,7 @@ class CBFSSM(BaseModel):
 
     def _make_engine(self, sess, dist):
         from ..hip.train import HipElboGrad, PARAM_NAMES
-        return HipElboGrad(self.config, sess.device, dist, require_adjoint=False), PARAM_NAMES
+        return HipElboGrad(self.config, sess.device, dist, require_adjoint=False, dtype=self.dtype), PARAM_NAMES
 
     def _state_dict(self):
         sd = self._opt.state_dict()

@@ -310,6 +310,20 @@ struct Tile {
     static constexpr int LDS_DOUBLES = DK * 64 + MP * 16 + W * 512 + 64 + TRI_LDS;   // per column block (+64 once)
     static constexpr int NBR = BREG ? (TRI ? KS + 4 : KS) : 1;            // loop-invariant matrix operands in VGPRs
     static_assert(!(TRI && BREG) || RB == 1, "register-resident triangular operands: one row block per wave");
+
+    // Row block(s) of wave w.  Dense form: w RB + i.  Two-triangular form with register operands: row block rb costs
+    // 4 (rb + 1) k-steps in the first product and KS - 4 rb in the second, so which waves SHARE A SIMD matters (waves go
+    // to the four SIMDs round robin: w & 3).  At seven row blocks the pairs (5,0), (4,1), (3,2) carry 28 k-steps of the
+    // first product each and the longest row block (6) sits alone on the fourth SIMD: every A row block is complete
+    // after about 28 MFMA slots instead of about 50 with the identity map, and the second product rarely waits.
+    __device__ __forceinline__ static int rb_of(int w, int i)
+    {
+        if constexpr (TRI && BREG && NBLK == 7) {
+            return (w == 3) ? 6 : ((w < 3) ? 5 - w : w - 4);       // w: 0..6 -> 5, 4, 3, 6, 0, 1, 2
+        } else {
+            return w * RB + i;
+        }
+    }
     // pass_kernel<NC = 1>, streamed K^-1: how many of the mean / variance operand images fit into LDS next to the tiles
     static constexpr int EPI_LDS_N = BREG ? 0 : (LDS_DOUBLES + 2 * NBLK * 256 <= 20480 ? 2 : (LDS_DOUBLES + NBLK * 256 <= 20480 ? 1 : 0));
     static constexpr bool EPI_LDS = EPI_LDS_N > 0;
@@ -343,7 +357,7 @@ struct Tile {
         KSr = pk.KSr;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int rb = w * RB + i;
+            const int rb = rb_of(w, i);
             const bool ok = rb < NBLK;
             const int rbc = ok ? rb : 0;
 #pragma unroll
@@ -361,7 +375,7 @@ struct Tile {
                 for (int s = 0; s < KS; ++s) Breg[i][s] = ok ? pk.Bp[(rbc * KS + s) * 64 + l] : 0.0;
             }
         }
-        if constexpr (BREG && TRI) load_tri_dispatch<0>(pk, __builtin_amdgcn_readfirstlane(w), l);
+        if constexpr (BREG && TRI) load_tri_dispatch<0>(pk, __builtin_amdgcn_readfirstlane(rb_of(w, 0)), l);
     }
 
     // register-resident triangular operands of the wave that owns row block RBI: 4 (RBI + 1) k-steps of W's row block
@@ -386,12 +400,15 @@ struct Tile {
     }
 
     // ---- phase 2 in the two-triangular form.  epilogue shared by both operand sources: a2 rows -> P1/P2 partials
-    __device__ __forceinline__ void tri_epilogue(const d4 (&a2)[RB], double q, double* part, int w, int l, double* a2o)
+    // slot: this wave's slot of the partial tiles (its index); rb0: its first row block
+    __device__ __forceinline__ void tri_epilogue(const d4 (&a2)[RB], double q, double* part, int slot, int rb0, int l,
+                                                 double* a2o)
     {
+        const int w = slot;
         d4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int rb = w * RB + i;
+            const int rb = rb0 + i;
             if (rb < NBLK) {
                 if (a2o) {
 #pragma unroll
@@ -415,20 +432,32 @@ struct Tile {
         }
     }
 
-    // operands in VGPRs (NBLK <= 7, one row block per wave); RBI = the wave's row block
+    // operands in VGPRs (NBLK <= 7, one row block per wave); RBI = the wave's row block.  Straight-line code: only the
+    // k-steps of the LAST row block are guarded by the number of k-steps that carry data (the images are zero beyond M,
+    // so the others are at worst products with zeros, and a guard per MFMA would cut the loop into basic blocks whose
+    // LDS reads cannot be issued ahead).
     template <int RBI>
     __device__ __forceinline__ void phase2_tri_reg(const double* Kt, double* At, int* flag, int epoch, double* part, int l,
-                                                   double* a2o)
+                                                   int slot, double* a2o)
     {
         constexpr int N1 = 4 * (RBI + 1);
+        constexpr int NFULL = (RBI == NBLK - 1) ? N1 - 4 : N1;          // k-steps that need no guard
         // A rows of this block: W[RBI, 0..RBI] K[0..RBI]                                         (gp_tf.py:137)
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < N1; ++s) {
-            if (s < KSr) {
-                const double b = Kt[64 * s + l];
-                if (s & 1) acc1 = CBF_MFMA(Breg[0][s], b, acc1);
-                else acc0 = CBF_MFMA(Breg[0][s], b, acc0);
+        for (int s = 0; s < NFULL; ++s) {
+            const double b = Kt[64 * s + l];
+            if (s & 1) acc1 = CBF_MFMA(Breg[0][s], b, acc1);
+            else acc0 = CBF_MFMA(Breg[0][s], b, acc0);
+        }
+        if constexpr (RBI == NBLK - 1) {
+#pragma unroll
+            for (int s = NFULL; s < N1; ++s) {
+                if (s < KSr) {
+                    const double b = Kt[64 * s + l];
+                    if (s & 1) acc1 = CBF_MFMA(Breg[0][s], b, acc1);
+                    else acc0 = CBF_MFMA(Breg[0][s], b, acc0);
+                }
             }
         }
         const d4 A = acc0 + acc1;
@@ -444,37 +473,35 @@ struct Tile {
         d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (4 * RBI + r < KSr) {
+            if (RBI < NBLK - 1 || 4 * RBI + r < KSr) {
                 if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + r], A[r], c1);
                 else c0 = CBF_MFMA(Breg[0][N1 + r], A[r], c0);
             }
         }
 #pragma unroll
         for (int kb = RBI + 1; kb < NBLK; ++kb) {
-            if (4 * kb < KSr) {
-                flag_wait(flag + kb, epoch);
+            flag_wait(flag + kb, epoch);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int s = 4 * kb + r;
-                    if (s < KSr) {
-                        const double b = At[64 * s + l];
-                        if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c1);
-                        else c0 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c0);
-                    }
+            for (int r = 0; r < 4; ++r) {
+                const int s = 4 * kb + r;
+                if (kb < NBLK - 1 || s < KSr) {
+                    const double b = At[64 * s + l];
+                    if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c1);
+                    else c0 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c0);
                 }
             }
         }
         d4 a2[RB];
         a2[0] = c0 + c1;
-        tri_epilogue(a2, q, part, RBI, l, a2o);
+        tri_epilogue(a2, q, part, slot, RBI, l, a2o);
     }
     template <int I>
     __device__ __forceinline__ void phase2_tri_dispatch(const double* Kt, double* At, int* flag, int epoch, double* part,
-                                                        int wu, int l, double* a2o)
+                                                        int rbu, int slot, int l, double* a2o)
     {
         if constexpr (I < NBLK) {
-            if (wu == I) phase2_tri_reg<I>(Kt, At, flag, epoch, part, l, a2o);
-            else phase2_tri_dispatch<I + 1>(Kt, At, flag, epoch, part, wu, l, a2o);
+            if (rbu == I) phase2_tri_reg<I>(Kt, At, flag, epoch, part, l, slot, a2o);
+            else phase2_tri_dispatch<I + 1>(Kt, At, flag, epoch, part, rbu, slot, l, a2o);
         }
     }
 
@@ -543,13 +570,13 @@ struct Tile {
         d4 a2[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) a2[i] = c[i][0] + c[i][1];
-        tri_epilogue(a2, q, part, w, l, a2o);
+        tri_epilogue(a2, q, part, w, w * RB, l, a2o);
     }
 
     __device__ __forceinline__ void phase2_tri(const double* Kt, double* At, int* flag, int epoch, double* part, int w, int l,
                                                double* a2o = nullptr)
     {
-        if constexpr (BREG) phase2_tri_dispatch<0>(Kt, At, flag, epoch, part, __builtin_amdgcn_readfirstlane(w), l, a2o);
+        if constexpr (BREG) phase2_tri_dispatch<0>(Kt, At, flag, epoch, part, __builtin_amdgcn_readfirstlane(rb_of(w, 0)), w, l, a2o);
         else phase2_tri_stream(Kt, At, flag, epoch, part, w, l, a2o);
     }
 
@@ -695,7 +722,7 @@ struct Tile {
         xx += __shfl_xor(xx, 32);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int rb = w * RB + i;
+            const int rb = rb_of(w, i);
             if (rb < NBLK) {
                 d4 e;
 #pragma unroll

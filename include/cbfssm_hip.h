@@ -283,6 +283,31 @@ int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* st
                               double* work, double* ginv_image, void* stream);
 
 /*
+ * float32-ARITHMETIC variant of the forward evaluation (BASELINE.json configs[4]; the reference's model dtype argument,
+ * cbfssm.py:12: `CBFSSM(config, dtype=tf.float32)`).  As in the reference's float32 mode the Cholesky of K_mm is computed
+ * in float64 and cast (gp_tf.py:57-65): the operands are the float64 pack of cbfssm_gp_prepare_f64 re-packed as float32
+ * MFMA images; kernel tile, exp, the K^-1 K contraction (v_mfma_f32_16x16x4_f32) and the step epilogues are float32.
+ * Storage stays float64: u, y, noise, trajectories and partial sums are the buffers of the float64 entry points.
+ *   cbfssm_pack_f32_elems   floats of a float32 pack for this layout (host)
+ *   cbfssm_gp_pack_f32      float64 pack -> float32 pack (after every cbfssm_gp_prepare*_f64)
+ *   cbfssm_gp_predict_f32   GPModel.predict (gp_tf.py:132-161)
+ *   cbfssm_backward_pass_f32 / cbfssm_forward_pass_f32   CBFSSM._backward / _forward (cbfssm.py:84-237); the partial-sum
+ *                           buffers have cbfssm_backward_pass_partials / cbfssm_forward_pass_partials entries; feed
+ *                           cbfssm_loglik_moments_f64 and cbfssm_elbo_combine_f64 as usual.
+ * Forward evaluation only: there is no float32 adjoint (training runs in float64).
+ */
+int64_t cbfssm_pack_f32_elems(const cbfssm_pack_layout* layout);
+int cbfssm_gp_pack_f32(const cbfssm_pack_layout* layout, const double* pack, float* pack32, void* stream);
+int cbfssm_gp_predict_f32(const cbfssm_pack_layout* layout, const float* pack32, const double* X, int64_t npts,
+                          double* fmean, double* fvar, void* stream);
+int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const float* pack32_b,
+                             const double* var_x, const double* u, const double* y, const double* hid_b,
+                             const double* eps_b, double* y2, double* ent_part, void* stream);
+int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
+                            const double* var_x, const double* var_y, const double* u, const double* y,
+                            const double* y2, const double* eps_f, double* x, double* kl_part, void* stream);
+
+/*
  * ---- once-per-step tail of a train step ------------------------------------------------------------------------------
  * The twelve trainable tensors of CBFSSM._setup_vars (cbfssm.py:30-58) as ONE flat float64 vector, in this order:
  *   f.zeta_pos (M,D) f.zeta_mean (M,dim_x) f.zeta_var_unc (M,dim_x) f.variance_unc (1) f.lengthscales_unc (D)

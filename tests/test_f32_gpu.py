@@ -1,0 +1,128 @@
+"""float32-arithmetic forward evaluation (cbfssm_*_f32: v_mfma_f32_16x16x4_f32, Cholesky kept in float64 as the
+reference's float32 models do, gp_tf.py:57-65) against the float64 kernels and the oracle: it is a reduced-precision
+path, the tolerances say how much it loses -- BASELINE.json configs[4] asks for exactly that sweep."""
+import dataclasses
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+from cbfssm import synthetic as syn
+from cbfssm.hip import ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('M,dim_x,dim_u,dim_y', [(12, 5, 2, 2), (20, 4, 1, 1), (50, 4, 1, 1), (100, 14, 7, 7),
+                                                (130, 9, 3, 2), (200, 14, 7, 7), (250, 4, 2, 2), (300, 4, 2, 2)])
+def test_gp_predict_f32_every_tile_height(M, dim_x, dim_u, dim_y):
+    from test_hip_parity import _gp_args
+    w = syn.tiny(M=M, dim_x=dim_x, dim_u=dim_u, dim_y=dim_y)
+    p = syn.perturb_params(syn.make_params(w, seed=M))
+    rng = np.random.default_rng(7)
+    for g, Do in (('f', dim_x), ('b', dim_x - dim_y)):
+        pack = ops.GPPack(M, w.D, Do, DEV, 'dense').prepare(*[torch.tensor(a, device=DEV) for a in _gp_args(p, g)])
+        for npts in (1, 16, 37):
+            X = torch.tensor(rng.standard_normal((npts, w.D)) * 1.5, device=DEV)
+            fm, fv = pack.predict(X)
+            fm32, fv32 = pack.predict_f32(X)
+            # one GP conditional in float32: ~1e-6 of the scale of the outputs (sigma^2 for the variance)
+            np.testing.assert_allclose(fm32.cpu().numpy(), fm.cpu().numpy(), rtol=0, atol=2e-5 * float(fm.abs().max()) + 1e-7)
+            np.testing.assert_allclose(fv32.cpu().numpy(), fv.cpu().numpy(), rtol=0, atol=2e-5 * float(fv.abs().max()))
+
+
+@pytest.mark.parametrize('kw', [
+    dict(M=100, dim_x=14, dim_u=7, dim_y=7, T=20, B=2, S=20, recog_len=4, k_factor=50., var_y=0.05 ** 2),   # Sarcos tile
+    dict(M=200, dim_x=14, dim_u=7, dim_y=7, T=9, B=1, S=20, recog_len=2, k_factor=50.),                     # C4 tile
+    dict(M=300, dim_x=4, dim_u=2, dim_y=2, T=60, B=2, S=9, recog_len=10, k_factor=1.),                      # C5 tile
+    dict(M=20, dim_x=4, dim_u=1, dim_y=1, T=50, B=3, S=50, recog_len=16, k_factor=100., gp_len=2.),         # C1 tile
+    dict(M=12, dim_x=5, dim_u=2, dim_y=2, T=11, B=3, S=4, recog_len=3, k_factor=3.),                        # ragged chains
+])
+@pytest.mark.parametrize('cond', [True, False])
+def test_elbo_f32_tracks_f64(kw, cond):
+    w = syn.tiny(loss_factors=(2., 0.7), **kw)
+    cfg = w.model_config()
+    p = syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)
+    u, y = syn.make_inputs(w, seed=0)
+    noise = syn.make_noise(w, seed=2)
+    e64, e32 = ops.HipElbo(cfg, DEV), ops.HipElbo(cfg, DEV, dtype='float32')
+    e64.prepare(p)
+    e32.prepare(p)
+    o64 = e64.run(u, y, noise, condition=cond)
+    o32 = e32.run(u, y, noise, condition=cond)
+    a, b = o64.out.cpu().numpy(), o32.out.cpu().numpy()
+    assert b[7] == 0.0
+    for i, name in enumerate(('loglik', 'kl_x', 'entropy')):
+        assert b[i] == pytest.approx(a[i], rel=2e-4, abs=1e-3), name
+    assert b[3] == a[3] and b[4] == a[4]                    # the prior KL comes from the float64 prepare
+    assert b[6] == pytest.approx(a[6], rel=2e-4)
+    x64, x32 = o64.x.cpu().numpy(), o32.x.cpu().numpy()
+    assert np.abs(x32 - x64).max() <= 2e-3 * np.abs(x64).max()
+    np.testing.assert_allclose(o32.pred_mean.cpu().numpy(), o64.pred_mean.cpu().numpy(), rtol=0,
+                               atol=2e-3 * float(o64.pred_mean.abs().max()))
+    # a second evaluation is bit-identical
+    out1 = o32.out.clone()
+    o32 = e32.run(u, y, noise, condition=cond)
+    assert torch.equal(out1, o32.out)
+
+
+def test_f32_model_surface(tmp_path):
+    """CBFSSM(config, dtype='float32') (cbfssm.py:12): loss and predictions through the float32 passes; train raises"""
+    from cbfssm.datasets import make_synthetic_ds
+    from cbfssm.model import CBFSSM
+    from cbfssm.model.session import Session
+    ds_sel = make_synthetic_ds(dim_u=1, dim_y=1, n_train=200, n_test=80, seed=1)
+    dim_x = 3
+    cfg = {'ds': ds_sel, 'batch_size': 4, 'shuffle': 100, 'seed': 3, 'dim_x': dim_x, 'ind_pnt_num': 20, 'samples': 10,
+           'learning_rate': 0.05, 'loss_factors': np.asarray([1., 0.]), 'k_factor': 5., 'recog_len': 8, 'zeta_pos': 2.,
+           'zeta_mean': 0.05 ** 2, 'zeta_var': 0.01 ** 2, 'var_x': np.asarray([0.002 ** 2] * dim_x),
+           'var_y': np.asarray([1. ** 2] * dim_x), 'gp_var': 0.5 ** 2, 'gp_len': 2.}
+    ds = ds_sel(40, 20)
+    res = {}
+    for dt in ('float64', 'float32'):
+        m = CBFSSM(dict(cfg), dtype=dt)
+        with m.graph.as_default(), Session() as sess:
+            sess.run(m.init)
+            m.load_ds(sess, ds.train_in_batch, ds.train_out_batch)
+            res[dt] = m.run(sess, (m.loss, m.pred_mean), {m.condition: True})
+            if dt == 'float32':
+                m.load_ds(sess, ds.train_in_batch, ds.train_out_batch)
+                with pytest.raises(NotImplementedError):
+                    sess.run((m.train, m.loss), feed_dict={m.condition: True})
+    np.testing.assert_allclose(res['float32'][0], res['float64'][0], rtol=1e-3)
+    np.testing.assert_allclose(res['float32'][1], res['float64'][1], rtol=0, atol=5e-3 * np.abs(res['float64'][1]).max())
+
+
+def test_precision_sweep_c5_shape_on_the_gpu():
+    """BASELINE.json configs[4]: the ELBO / predictive-moment error of float32 arithmetic against float64 on the
+    RoboMove-shaped problem (M = 300, T = 1000, S = 50, recog_len = 50; B = 8 here), at the run-script initial values and
+    at trained-like parameters.  The numbers go to gpurun_out/precision_sweep_gpu.json (quoted in DESIGN.md)."""
+    w = dataclasses.replace(syn.WORKLOADS['C5'], B=8)
+    cfg = w.model_config()
+    u, y = syn.make_inputs(w, seed=0)
+    noise = syn.make_noise(w, seed=2)
+    report = {}
+    for tag, p in (('initial', syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)),
+                   ('trained_like_ls_x2', syn.trained_like_params(w, ls_mult=2.0, zeta_mean=0.05)),
+                   ('trained_like_ls_x3', syn.trained_like_params(w, ls_mult=3.0, zeta_mean=0.05))):
+        e64, e32 = ops.HipElbo(cfg, DEV), ops.HipElbo(cfg, DEV, dtype='float32')
+        e64.prepare(p)
+        e32.prepare(p)
+        o64 = e64.run(u, y, noise, condition=True)
+        o32 = e32.run(u, y, noise, condition=True)
+        a, b = o64.out.cpu().numpy(), o32.out.cpu().numpy()
+        pm64, pv64 = o64.pred_mean.cpu().numpy(), o64.pred_var.cpu().numpy()
+        rep = {'cond_f': float(e64.pack_f.scal[4]), 'cond_b': float(e64.pack_b.scal[4]),
+               'loss_rel': float(abs(b[6] - a[6]) / abs(a[6])),
+               'pred_mean_relmax': float(np.abs(o32.pred_mean.cpu().numpy() - pm64).max() / np.abs(pm64).max()),
+               'pred_var_rel': float((np.abs(o32.pred_var.cpu().numpy() - pv64) / pv64).max())}
+        report[tag] = rep
+        print('\nC5-shape (B=8) float32 vs float64, %s: cond f %.1e b %.1e | loss %.1e pred_mean %.1e pred_var %.1e'
+              % (tag, rep['cond_f'], rep['cond_b'], rep['loss_rel'], rep['pred_mean_relmax'], rep['pred_var_rel']))
+        assert np.isfinite(b[6])
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    json.dump(report, open(os.path.join(out, 'precision_sweep_gpu.json'), 'w'), indent=1)
+    assert report['initial']['loss_rel'] <= 1e-4

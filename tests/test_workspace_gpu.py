@@ -66,7 +66,7 @@ def test_ragged_batch_gradient_is_the_same_with_shared_tiles():
 
 
 def test_shape_over_the_budget_falls_back_loudly(monkeypatch):
-    monkeypatch.setenv('CBFSSM_A2S_MAX_GB', '0.001')
+    monkeypatch.setenv('CBFSSM_A2S_MAX_GB', '0.0001')      # 107 KB: the tiles of this shape need 770 KB
     w = syn.tiny(M=20, T=16, B=8, S=8)
     cfg = w.model_config()
     p = {k: torch.tensor(v, device=DEV) for k, v in syn.make_params(w).items()}
