@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    kreg[i][r] = exp(e[r]);
+                    kreg[i][r] = tile_exp(e[r]);
                     Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
                 }
             }

@@ -434,18 +434,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
                     if (MODE == MODE_FWD) {
                         const float vyt = vy[qi] + (a.k_factor - 1.0f) * fvar;             // cbfssm.py:212-214
                         const float sm = vyt + fvar;
-                        const float kk = fvar * rcp32(sm);
+                        const float rs = rcp32(sm);
+                        const float kk = fvar * rs;
                         const float ydiff = ytil[qi] - fmean;
                         const float mu = fmean + kk * ydiff;
-                        const float omk = 1.0f - kk;
-                        const float sig = omk * omk * fvar + kk * kk * vyt;                // :219-220
+                        const float sig = kk * vyt;                 // = (1-k)^2 fvar + k^2 v with 1 - k = v / s   (:219-220)
                         const bool do_cond = a.condition || (t < R - 1);                   // :227
                         outv = do_cond ? (mu + eps_t * (sig * rsqrt32(sig))) : (fmean + eps_t * (fvar * rsqrt32(fvar)));
                         if (do_cond && cval) {
-                            const float rf = rcp32(fvar);
-                            const float dm = mu - fmean;
-                            lin[qi] += double((sig + dm * dm) * rf - 1.0f);                // :232
-                            lp[qi].mul(double(sig * rf));
+                            lin[qi] += double(kk * (ydiff * ydiff * rs - 1.0f));           // (sig + (mu-fmean)^2)/fvar - 1  (:232)
+                            lp[qi].mul(double(vyt * rs));                                  // sig / fvar
                         }
                         if (cval) a.x_out[(int64_t(t + 1) * N + c) * a.dim_x + d] = double(outv);
                     } else {

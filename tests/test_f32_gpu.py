@@ -28,9 +28,9 @@ def test_gp_predict_f32_every_tile_height(M, dim_x, dim_u, dim_y):
             X = torch.tensor(rng.standard_normal((npts, w.D)) * 1.5, device=DEV)
             fm, fv = pack.predict(X)
             fm32, fv32 = pack.predict_f32(X)
-            # one GP conditional in float32: ~1e-6 of the scale of the outputs (sigma^2 for the variance)
-            np.testing.assert_allclose(fm32.cpu().numpy(), fm.cpu().numpy(), rtol=0, atol=2e-5 * float(fm.abs().max()) + 1e-7)
-            np.testing.assert_allclose(fv32.cpu().numpy(), fv.cpu().numpy(), rtol=0, atol=2e-5 * float(fv.abs().max()))
+            # one GP conditional in float32: a few 1e-5 of the scale of the outputs (sigma^2 for the variance) at M = 250
+            np.testing.assert_allclose(fm32.cpu().numpy(), fm.cpu().numpy(), rtol=0, atol=1e-4 * float(fm.abs().max()) + 1e-7)
+            np.testing.assert_allclose(fv32.cpu().numpy(), fv.cpu().numpy(), rtol=0, atol=1e-4 * float(fv.abs().max()))
 
 
 @pytest.mark.parametrize('kw', [
