@@ -63,3 +63,43 @@ def test_two_rank_gloo_allreduce_and_identical_iteration_order():
     assert out[0][0] and out[1][0]
     assert out[0][1] == out[1][1] == 100          # rank 0's seed wins
     assert out[0][2] and out[1][2]
+
+
+def _worker_params(rank, world, port, out, tmp):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from cbfssm.hip.dist_utils import broadcast_tensor, is_writer, barrier, active
+        # every rank draws its own (unseeded) initial values; rank 0's win
+        flat = torch.full((1000,), float(rank + 1), dtype=torch.float64) + torch.rand(1000, dtype=torch.float64)
+        mine = flat.clone()
+        broadcast_tensor(flat, dist, src=0)
+        gathered = [torch.zeros(1000, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = all(torch.equal(gathered[0], g) for g in gathered)
+        # a rank with an empty shard joins the one all-reduce with weight 0
+        red = torch.arange(8, dtype=torch.float64) * (rank + 1)
+        weight = 1.0 if rank == 0 else 0.0
+        red.mul_(weight)
+        all_reduce_sum(red, dist)
+        ok_w = bool(torch.equal(red, torch.arange(8, dtype=torch.float64)))
+        # rank 0 writes, the others wait for the file
+        path = os.path.join(tmp, 'ckpt')
+        if is_writer():
+            with open(path, 'w') as f:
+                f.write('x')
+        barrier()
+        out[rank] = (same, bool(torch.equal(flat, mine)) == (rank == 0), ok_w, is_writer() == (rank == 0),
+                     os.path.exists(path), active() is not None)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_parameter_broadcast_zero_weight_shard_and_single_writer(tmp_path):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_params, args=(world, _free_port(), out, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        assert all(out[rank]), (rank, out[rank])
