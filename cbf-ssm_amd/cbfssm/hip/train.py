@@ -69,7 +69,7 @@ class StashContract:
     def add(self, sa, sk, cols, stream):
         lib = _l.load()
         nslots = cols // 16
-        if nslots <= 0:
+        if nslots <= 0 or os.environ.get('CBFSSM_DIAG_SKIP_CONTRACT'):     # (diagnostic: what the contraction costs a step)
             return
         need = int(lib.cbfssm_stash_contract_work_elems(C.byref(self.pack.layout), nslots))
         if self.work is None or self.work.numel() < need:

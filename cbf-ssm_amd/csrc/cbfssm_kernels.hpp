@@ -776,16 +776,12 @@ struct Tile {
 #pragma unroll
         for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
         if constexpr (BREG) {
-            // (the last three k-steps may be all padding -- K^-1 columns beyond M, e.g. 25 of 28 carry data at M = 100:
-            //  only those are guarded, the straight-line part keeps its LDS reads issued ahead)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                if (s < KS - 3 || s < KSr) {
-                    const double b = Kt[64 * s + l];
+                const double b = Kt[64 * s + l];
 #pragma unroll
-                    for (int i = 0; i < RB; ++i)
-                        if (w * RB + i < NBLK) acc[i][s & 1] = CBF_MFMA(Breg[i][s], b, acc[i][s & 1]);
-                }
+                for (int i = 0; i < RB; ++i)
+                    if (w * RB + i < NBLK) acc[i][s & 1] = CBF_MFMA(Breg[i][s], b, acc[i][s & 1]);
             }
         } else if constexpr (RB == 2) {
             // (a wave whose second row block does not exist runs it on a copy of the last block; the result is dropped)
