@@ -102,6 +102,85 @@ __global__ __launch_bounds__(64 * contract_waves(NBLK)) void stash_contract_kern
     }
 }
 
+
+// Second form, for the tile heights whose accumulator fits ONE workgroup (NBLK <= 13: two row blocks per wave, 2 x NBLK
+// accumulator tiles = 208 VGPRs at NBLK = 13): every slot's two operand images (A2bar^T and K^T, 2 x NBLK x 2 KiB) are read
+// from HBM exactly once -- the row-group form above reads the K^T image once per row group, 78 KB per slot instead of 53 KB
+// at NBLK = 13, and the contraction runs against the adjoint kernels' own stash writes on the other stream: it is
+// bandwidth-bound there (1.5 TB/s of reads next to 1 TB/s of writes).  Both images arrive by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging registers -- the accumulators own the register file),
+// two LDS buffers, the copies of slot s+1 in flight under the 2 x 4 x NBLK MFMAs of slot s; every K^T operand read from LDS
+// feeds both row blocks of the wave.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int NBLK>
+__global__ __launch_bounds__(64 * ((NBLK + 1) / 2)) void stash_contract2_kernel(const double* __restrict__ sa,
+                                                                              const double* __restrict__ sk, int64_t nslots,
+                                                                              int64_t slots_per_wg, double* __restrict__ part)
+{
+    constexpr int W = (NBLK + 1) / 2;
+    constexpr int IMG = NBLK * 256;                     // doubles of one operand image (one slot)
+    constexpr int PIMG = IMG / 128;                     // 1-KiB pieces per image
+    extern __shared__ double lds[];                     // [2][A image | B image]
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int rb0 = 2 * w, rb1 = min(2 * w + 1, NBLK - 1);      // (the last wave of an odd NBLK repeats its block; dropped)
+    const bool valid1 = 2 * w + 1 < NBLK;
+    const int64_t s_begin = int64_t(blockIdx.x) * slots_per_wg;
+    const int64_t s_end = (s_begin + slots_per_wg < nslots) ? s_begin + slots_per_wg : nslots;
+
+    d4 acc0[NBLK], acc1[NBLK];
+#pragma unroll
+    for (int cb = 0; cb < NBLK; ++cb) { acc0[cb] = d4{0, 0, 0, 0}; acc1[cb] = d4{0, 0, 0, 0}; }
+
+    auto stage = [&](int64_t slot, int buf) {
+        double* dst = lds + buf * 2 * IMG;
+#pragma unroll
+        for (int k = 0; k < (2 * PIMG + W - 1) / W; ++k) {
+            const int p = w + k * W;                    // piece of this wave: A image pieces first, then the B image
+            if (p < 2 * PIMG) {
+                const double* src = (p < PIMG) ? sa + slot * IMG + p * 128 : sk + slot * IMG + (p - PIMG) * 128;
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 2 * l), (lds_void_t*)(dst + p * 128), 16, 0, 0);
+            }
+        }
+    };
+
+    if (s_begin < s_end) {
+        stage(s_begin, 0);
+        __syncthreads();                                 // (its fence waits for the LDS-DMA: vmcnt(0))
+        for (int64_t slot = s_begin; slot < s_end; ++slot) {
+            const int buf = int(slot - s_begin) & 1;
+            if (slot + 1 < s_end) stage(slot + 1, buf ^ 1);       // read last in the previous iteration, before its barrier
+            const double* A = lds + buf * 2 * IMG + l;
+            const double* B = A + IMG;
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {                // (not unrolled: the B reads of one k-step ahead of their MFMAs
+                                                         //  are what fits next to 208 accumulator registers)
+                const double a0 = A[rb0 * 256 + s * 64], a1 = A[rb1 * 256 + s * 64];
+#pragma unroll
+                for (int cb = 0; cb < NBLK; ++cb) {
+                    const double b = B[(cb * 4 + s) * 64];
+                    acc0[cb] = CBF_MFMA(a0, b, acc0[cb]);
+                    acc1[cb] = CBF_MFMA(a1, b, acc1[cb]);
+                }
+            }
+            __syncthreads();                             // next slot's images landed (vmcnt(0)), this buffer free
+        }
+    }
+    double* o0 = part + (int64_t(blockIdx.x) * NBLK * NBLK + int64_t(rb0) * NBLK) * 256 + l;
+#pragma unroll
+    for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o0[cb * 256 + r * 64] = acc0[cb][r];
+    if (valid1) {
+        double* o1 = part + (int64_t(blockIdx.x) * NBLK * NBLK + int64_t(rb1) * NBLK) * 256 + l;
+#pragma unroll
+        for (int cb = 0; cb < NBLK; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o1[cb * 256 + r * 64] = acc1[cb][r];
+    }
+}
+
 // out[i] += sum_k part[k][i] in a fixed order
 __global__ void contract_reduce_kernel(const double* part, int64_t n, int nsplit, double* out)
 {
@@ -136,6 +215,20 @@ static int launch_contract(const double* sa, const double* sk, int64_t nslots, d
     const int64_t per = (nslots + nsplit - 1) / nsplit;
     constexpr int CONTRACT_WAVES = contract_waves(NBLK);
     const int nrg = (NBLK + CONTRACT_WAVES - 1) / CONTRACT_WAVES;
+    if constexpr (NBLK <= 13) {
+        if (!getenv("CBFSSM_CONTRACT_V1")) {            // (measurement switch: the row-group form)
+            const size_t lds2 = size_t(4) * NBLK * 256 * sizeof(double);
+            auto k2 = stash_contract2_kernel<NBLK>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds2));
+            if (e != hipSuccess) return -int(e) - 1000;
+            hipLaunchKernelGGL(k2, dim3(unsigned(nsplit), 1), dim3(64 * ((NBLK + 1) / 2)), lds2, st, sa, sk, nslots, per, work);
+            const int64_t n2 = int64_t(NBLK) * NBLK * 256;
+            hipLaunchKernelGGL(contract_reduce_kernel, dim3(unsigned((n2 + 255) / 256)), dim3(256), 0, st, (const double*)work, n2,
+                               nsplit, out);
+            e = hipGetLastError();
+            return e == hipSuccess ? 0 : -int(e) - 1000;
+        }
+    }
     const size_t lds = size_t(2) * NBLK * 256 * sizeof(double);
     auto k = stash_contract_kernel<NBLK>;
     if (lds > 48 * 1024) {
