@@ -27,22 +27,28 @@ inline int set_lds(K kernel, size_t bytes)
     return 0;
 }
 
-template <int NBLK, int DK>
-int launch_predict_t(const PredictArgs& a, hipStream_t st)
+// Register-resident tiles of seven row blocks (M = 97..112, the Sarcos class) are instantiated once per number of
+// all-padding k-steps (KT = 0..3) so that their loops end at the last k-step that carries data without a runtime guard;
+// everything else runs the unspecialised form (KT = -1).
+template <int NBLK>
+constexpr bool trim_tiles() { return NBLK == 7; }
+
+template <int NBLK, int DK, int KT>
+int launch_predict_k(const PredictArgs& a, hipStream_t st)
 {
     typedef Cfg<NBLK> C;
     const unsigned groups = unsigned((a.npts + 15) / 16);
     if (a.tri) {
-        typedef Tile<NBLK, C::RB, DK, C::BREG, true> TT;
+        typedef Tile<NBLK, C::RB, DK, C::BREG, true, KT> TT;
         const size_t lds = TT::LDS_DOUBLES * sizeof(double);
-        auto k = predict_kernel<NBLK, C::RB, DK, C::BREG, true>;
+        auto k = predict_kernel<NBLK, C::RB, DK, C::BREG, true, KT>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k, dim3(groups), dim3(TT::NT), lds, st, a);
     } else {
-        typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
+        typedef Tile<NBLK, C::RB, DK, C::BREG, false, KT> TT;
         const size_t lds = TT::LDS_DOUBLES * sizeof(double);
-        auto k = predict_kernel<NBLK, C::RB, DK, C::BREG>;
+        auto k = predict_kernel<NBLK, C::RB, DK, C::BREG, false, KT>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k, dim3(groups), dim3(TT::NT), lds, st, a);
@@ -51,11 +57,25 @@ int launch_predict_t(const PredictArgs& a, hipStream_t st)
     return e == hipSuccess ? 0 : -int(e) - 1000;
 }
 
-template <int NBLK, int DK, int MODE>
-int launch_pass_t(const PassArgs& a, dim3 grid, int nc, hipStream_t st)
+template <int NBLK, int DK>
+int launch_predict_t(const PredictArgs& a, hipStream_t st)
+{
+    if constexpr (trim_tiles<NBLK>()) {
+        switch (4 * NBLK - a.pk.KSr) {
+            case 0: return launch_predict_k<NBLK, DK, 0>(a, st);
+            case 1: return launch_predict_k<NBLK, DK, 1>(a, st);
+            case 2: return launch_predict_k<NBLK, DK, 2>(a, st);
+            case 3: return launch_predict_k<NBLK, DK, 3>(a, st);
+        }
+    }
+    return launch_predict_k<NBLK, DK, -1>(a, st);
+}
+
+template <int NBLK, int DK, int MODE, int KT>
+int launch_pass_k(const PassArgs& a, dim3 grid, int nc, hipStream_t st)
 {
     typedef Cfg<NBLK> C;
-    typedef Tile<NBLK, C::RB, DK, C::BREG> TT;
+    typedef Tile<NBLK, C::RB, DK, C::BREG, false, KT> TT;
     // nc: 1 = one 16-chain column block per workgroup; 2 = two blocks, skewed by half a step (pass_kernel_skew);
     //     3 = two blocks sharing every K^-1 operand load (pass_kernel<NC = 2>: the streamed-K^-1 tiles)
     const size_t lds = (size_t(nc == 1 ? 1 : 2) * (TT::LDS_DOUBLES - 64) + 64 + (nc == 1 ? TT::EPI_LDS_DOUBLES : 0)) *
@@ -63,30 +83,50 @@ int launch_pass_t(const PassArgs& a, dim3 grid, int nc, hipStream_t st)
     hipError_t e;
     if (a.tri) {
         // the reference's two-triangular form: one column block per workgroup (the caller passes nc = 1)
-        typedef Tile<NBLK, C::RB, DK, C::BREG, true> TR;
+        typedef Tile<NBLK, C::RB, DK, C::BREG, true, KT> TR;
         const size_t ldt = (size_t(TR::LDS_DOUBLES) + TR::EPI_LDS_DOUBLES) * sizeof(double);
-        auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 1, true>;
+        auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 1, true, KT>;
         int rc = set_lds(k, ldt);
         if (rc) return rc;
         hipLaunchKernelGGL(k, grid, dim3(TR::NT), ldt, st, a);
     } else if (nc == 3) {
-        auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 2>;
-        int rc = set_lds(k, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
+        if constexpr (KT < 0) {
+            auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 2>;
+            int rc = set_lds(k, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
+        } else {
+            return -2;      // (the shared-operand variant belongs to the streamed tiles: never trimmed)
+        }
     } else if (nc == 2) {
-        auto k = pass_kernel_skew<NBLK, C::RB, DK, C::BREG, MODE>;
+        auto k = pass_kernel_skew<NBLK, C::RB, DK, C::BREG, MODE, KT>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
     } else {
-        auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 1>;
+        auto k = pass_kernel<NBLK, C::RB, DK, C::BREG, MODE, 1, false, KT>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
     }
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
+}
+
+template <int NBLK, int DK, int MODE>
+int launch_pass_t(const PassArgs& a, dim3 grid, int nc, hipStream_t st)
+{
+    if constexpr (trim_tiles<NBLK>()) {
+        if (nc != 3) {
+            switch (4 * NBLK - a.pk.KSr) {
+                case 0: return launch_pass_k<NBLK, DK, MODE, 0>(a, grid, nc, st);
+                case 1: return launch_pass_k<NBLK, DK, MODE, 1>(a, grid, nc, st);
+                case 2: return launch_pass_k<NBLK, DK, MODE, 2>(a, grid, nc, st);
+                case 3: return launch_pass_k<NBLK, DK, MODE, 3>(a, grid, nc, st);
+            }
+        }
+    }
+    return launch_pass_k<NBLK, DK, MODE, -1>(a, grid, nc, st);
 }
 
 template <int NBLK>

@@ -327,16 +327,23 @@ struct PredictArgs {
 // A2 the blocks rb..NBLK-1 of A: NBLK + 1 blocks per row block in total, whoever owns it.  The A rows travel through
 // an LDS tile; a consumer waits for the producing wave's flag, not for a workgroup barrier, so wave rb starts its second
 // product when its own rows are done and meets the rows of the later blocks as they appear.
-template <int NBLK, int RB, int DK, bool BREG, bool TRI = false>
+// KT: compile-time trim of the register-resident tiles.  KT >= 0 promises that exactly KS - KT k-steps carry data (M in
+// (4 (KS - KT - 1), 4 (KS - KT)]): the loops end there with no runtime guard -- a guard on an MFMA cuts the straight-line
+// sequence into basic blocks and the LDS reads are no longer issued ahead (measured: forward kernels 2.6 -> 3.9 ms at C3).
+// KT = -1: not specialised, all KS k-steps of the zero-padded images (the small tiles; every streamed tile).
+template <int NBLK, int RB, int DK, bool BREG, bool TRI = false, int KT = -1>
 struct Tile {
     static constexpr int W = (NBLK + RB - 1) / RB;   // waves per workgroup
     static constexpr int NT = 64 * W;
     static constexpr int MP = 16 * NBLK;
-    static constexpr int KS = MP / 4;                // k-steps of the K^-1 K product
+    static constexpr int KS = MP / 4;                // k-steps of the K^-1 K product (stride of the operand images)
+    static constexpr bool EXACT = (KT >= 0);
+    static constexpr int KSE = EXACT ? KS - KT : KS;  // k-steps the register-resident loops execute
+    static_assert(!EXACT || (BREG && KT < 4), "the trim applies to register-resident tiles, within the last row block");
     static constexpr int QPW = (4 + W - 1) / W;      // state-row groups (4 rows each) per wave in phase 3
     static constexpr int TRI_LDS = TRI ? MP * 16 + 64 : 0;                 // A = L^-1 k tile + the waves' flags
     static constexpr int LDS_DOUBLES = DK * 64 + MP * 16 + W * 512 + 64 + TRI_LDS;   // per column block (+64 once)
-    static constexpr int NBR = BREG ? (TRI ? KS + 4 : KS) : 1;            // loop-invariant matrix operands in VGPRs
+    static constexpr int NBR = BREG ? (TRI ? KSE + 4 : KSE) : 1;          // loop-invariant matrix operands in VGPRs
     static_assert(!(TRI && BREG) || RB == 1, "register-resident triangular operands: one row block per wave");
 
     // Row block(s) of wave w.  Dense form: w RB + i.  Two-triangular form with register operands: row block rb costs
@@ -400,7 +407,7 @@ struct Tile {
             }
             if constexpr (BREG && !TRI) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) Breg[i][s] = ok ? pk.Bp[(rbc * KS + s) * 64 + l] : 0.0;
+                for (int s = 0; s < KSE; ++s) Breg[i][s] = ok ? pk.Bp[(rbc * KS + s) * 64 + l] : 0.0;
             }
         }
         if constexpr (BREG && TRI) load_tri_dispatch<0>(pk, __builtin_amdgcn_readfirstlane(rb_of(w, 0)), l);
@@ -412,11 +419,11 @@ struct Tile {
     template <int RBI>
     __device__ __forceinline__ void load_tri_reg(const PackPtrs& pk, int l)
     {
-        constexpr int N1 = 4 * (RBI + 1);
+        constexpr int N1 = (4 * (RBI + 1) < KSE) ? 4 * (RBI + 1) : KSE;
 #pragma unroll
         for (int s = 0; s < N1; ++s) Breg[0][s] = pk.Wp[(RBI * KS + s) * 64 + l];
 #pragma unroll
-        for (int j = 0; j < KS - 4 * RBI; ++j) Breg[0][N1 + j] = pk.WTp[(RBI * KS + 4 * RBI + j) * 64 + l];
+        for (int j = 0; j < KSE - 4 * RBI; ++j) Breg[0][N1 + j] = pk.WTp[(RBI * KS + 4 * RBI + j) * 64 + l];
     }
     template <int I>
     __device__ __forceinline__ void load_tri_dispatch(const PackPtrs& pk, int wu, int l)
@@ -468,8 +475,9 @@ struct Tile {
     __device__ __forceinline__ void phase2_tri_reg(const double* Kt, double* At, int* flag, int epoch, double* part, int l,
                                                    int slot, double* a2o)
     {
-        constexpr int N1 = 4 * (RBI + 1);
-        constexpr int NFULL = (RBI == NBLK - 1) ? N1 - 4 : N1;          // k-steps that need no guard
+        constexpr int N1 = (4 * (RBI + 1) < KSE) ? 4 * (RBI + 1) : KSE;
+        // without the compile-time trim the k-steps of the LAST row block are guarded by the count that carry data
+        constexpr int NFULL = (!EXACT && RBI == NBLK - 1) ? N1 - 4 : N1;
         // A rows of this block: W[RBI, 0..RBI] K[0..RBI]                                         (gp_tf.py:137)
         d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
@@ -478,7 +486,7 @@ struct Tile {
             if (s & 1) acc1 = CBF_MFMA(Breg[0][s], b, acc1);
             else acc0 = CBF_MFMA(Breg[0][s], b, acc0);
         }
-        if constexpr (RBI == NBLK - 1) {
+        if constexpr (NFULL < N1) {
 #pragma unroll
             for (int s = NFULL; s < N1; ++s) {
                 if (s < KSr) {
@@ -501,21 +509,33 @@ struct Tile {
         d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (RBI < NBLK - 1 || 4 * RBI + r < KSr) {
-                if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + r], A[r], c1);
-                else c0 = CBF_MFMA(Breg[0][N1 + r], A[r], c0);
+            if constexpr (EXACT) {
+                if (4 * RBI + r < KSE) {
+                    if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + r], A[r], c1);
+                    else c0 = CBF_MFMA(Breg[0][N1 + r], A[r], c0);
+                }
+            } else {
+                if (RBI < NBLK - 1 || 4 * RBI + r < KSr) {
+                    if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + r], A[r], c1);
+                    else c0 = CBF_MFMA(Breg[0][N1 + r], A[r], c0);
+                }
             }
         }
 #pragma unroll
         for (int kb = RBI + 1; kb < NBLK; ++kb) {
-            flag_wait(flag + kb, epoch);
+            if (4 * kb < KSE) {
+                flag_wait(flag + kb, epoch);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int s = 4 * kb + r;
-                if (kb < NBLK - 1 || s < KSr) {
-                    const double b = At[64 * s + l];
-                    if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c1);
-                    else c0 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c0);
+                for (int r = 0; r < 4; ++r) {
+                    const int s = 4 * kb + r;
+                    bool go;
+                    if constexpr (EXACT) go = s < KSE;
+                    else go = (kb < NBLK - 1) || (s < KSr);
+                    if (go) {
+                        const double b = At[64 * s + l];
+                        if (r & 1) c1 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c1);
+                        else c0 = CBF_MFMA(Breg[0][N1 + 4 * (kb - RBI) + r], b, c0);
+                    }
                 }
             }
         }
@@ -660,7 +680,7 @@ struct Tile {
             for (int i = 0; i < RB; ++i) { acc[c][i][0] = d4{0, 0, 0, 0}; acc[c][i][1] = d4{0, 0, 0, 0}; }
         if constexpr (BREG) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < KSE; ++s) {
                 double b[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) b[c] = Kt[c * KTS + 64 * s + l];
@@ -777,7 +797,7 @@ struct Tile {
         for (int i = 0; i < RB; ++i) { acc[i][0] = d4{0, 0, 0, 0}; acc[i][1] = d4{0, 0, 0, 0}; }
         if constexpr (BREG) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < KSE; ++s) {
                 const double b = Kt[64 * s + l];
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
@@ -882,10 +902,10 @@ struct LogProd {
 // ---------------------------------------------------------------------------------------------------------------------
 // GPModel.predict for arbitrary points (gp_tf.py:132-161)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBLK, int RB, int DK, bool BREG, bool TRI = false>
+template <int NBLK, int RB, int DK, bool BREG, bool TRI = false, int KT = -1>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(PredictArgs a)
 {
-    typedef Tile<NBLK, RB, DK, BREG, TRI> TT;
+    typedef Tile<NBLK, RB, DK, BREG, TRI, KT> TT;
     extern __shared__ double lds[];
     double* xq = lds;
     double* Kt = xq + DK * 64;
@@ -934,11 +954,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(Pr
 // MODE_BWD: one resample-to-resample segment of one CBFSSM._backward_body run (cbfssm.py:107-158).
 // NC: column blocks (16 chains each) per workgroup.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBLK, int RB, int DK, bool BREG, int MODE, int NC, bool TRI = false>
+template <int NBLK, int RB, int DK, bool BREG, int MODE, int NC, bool TRI = false, int KT = -1>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassArgs a)
 {
     static_assert(!TRI || NC == 1, "the two-triangular form runs one column block per workgroup");
-    typedef Tile<NBLK, RB, DK, BREG, TRI> TT;
+    typedef Tile<NBLK, RB, DK, BREG, TRI, KT> TT;
     constexpr int W = TT::W, NT = TT::NT;
     constexpr int NTASK = 4 * NC;                    // (state-row group q, column block) pairs of phase 3
     constexpr int QPW = (NTASK + W - 1) / W;
@@ -1240,10 +1260,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 //     gamma:  phase1(A, s+1)            ||  phase2(B, s)
 // Phase-3 work of A sits on the low waves, of B on the high waves (SIMD partners w, w+4 get different mixes).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NBLK, int RB, int DK, bool BREG, int MODE>
+template <int NBLK, int RB, int DK, bool BREG, int MODE, int KT = -1>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(PassArgs a)
 {
-    typedef Tile<NBLK, RB, DK, BREG> TT;
+    typedef Tile<NBLK, RB, DK, BREG, false, KT> TT;
     constexpr int W = TT::W, NT = TT::NT;
     constexpr int QPW = TT::QPW;                     // phase-3 tasks per wave and group
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
