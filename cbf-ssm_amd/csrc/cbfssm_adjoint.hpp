@@ -121,7 +121,9 @@ struct RevLds {
 constexpr int REV_XCB = 3;
 constexpr bool rev_extra_wave(int nblk, bool stash) { return nblk == 7 && !stash; }
 
-template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE>
+// KD: k-steps of the products whose k index is the GP output dimension (mu Fm, s2 Fv): 4 in general, 2 when the launcher
+// knows Do <= 8 (the backward runs of the Sarcos class: dim_x - dim_y = 7) -- the other two would multiply zeros.
+template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE, int KD = 4>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, STASH) ? 1 : 0))) void rev_kernel(RevArgs a)
 {
     constexpr bool BREG = false;
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         double fvsum = 0.0;
         double fmB[4], fvB[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KD; ++s) {                  // (rows d >= 4 KD of the Fm / Fv tiles are zero)
             fmB[s] = Fm[(4 * s + g) * PD + nl];
             fvB[s] = Fv[(4 * s + g) * PD + nl];
             fvsum += fvB[s];
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 const double* sBp = a.rk.s2B + rbs[i] * 256 + l;
                 d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                for (int s = 0; s < KD; ++s) {
                     T1 = CBF_MFMA(MUPRE ? mBv[s] : mBp[s * 64], fmB[s], T1);
                     T2 = CBF_MFMA(MUPRE ? sBv[s] : sBp[s * 64], fvB[s], T2);
                 }

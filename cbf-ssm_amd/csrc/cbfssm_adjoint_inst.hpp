@@ -26,8 +26,8 @@ struct RevGeom {
     static constexpr int SLAB = Slab<NBLK, JB, C::STASH>::total;
 };
 
-template <int NBLK, int DK, int MODE>
-int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
+template <int NBLK, int DK, int MODE, int KD>
+int launch_rev_k(const RevArgs& a, dim3 grid, hipStream_t st)
 {
     // K^-1 image in LDS when it fits next to the tiles (M <= 104 at NBLK = 7), else streamed from L2
     typedef RevGeom<NBLK, DK> G;
@@ -35,7 +35,7 @@ int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
     const int blds_doubles = NBLK * a.KSr * 64;
     if (G::LDS_BASE + blds_doubles <= G::LDS_LIMIT && !getenv("CBFSSM_NO_BLDS")) {
         const size_t lds = size_t(G::LDS_BASE + blds_doubles) * sizeof(double);
-        auto k = rev_kernel<NBLK, C::RB, DK, true, C::STASH, MODE>;
+        auto k = rev_kernel<NBLK, C::RB, DK, true, C::STASH, MODE, KD>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k, grid, dim3(64 * (C::W + (rev_extra_wave(NBLK, C::STASH) ? 1 : 0))), lds, st, a);
@@ -43,13 +43,23 @@ int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
         typedef RevLds<NBLK, C::RB, DK, C::STASH> RL;
         static_assert(RL::BASE_PLAIN == G::LDS_BASE, "LDS layout");
         const size_t lds = size_t(RL::BASE + RL::EXTRA) * sizeof(double);
-        auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE>;
+        auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE, KD>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(k, grid, dim3(64 * (C::W + (rev_extra_wave(NBLK, C::STASH) ? 1 : 0))), lds, st, a);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
+}
+
+template <int NBLK, int DK, int MODE>
+int launch_rev_t(const RevArgs& a, dim3 grid, hipStream_t st)
+{
+    // (seven row blocks = the Sarcos class: its backward runs carry dim_x - dim_y = 7 <= 8 output dimensions)
+    if constexpr (NBLK == 7) {
+        if (a.Do <= 8 && !getenv("CBFSSM_REV_KD4")) return launch_rev_k<NBLK, DK, MODE, 2>(a, grid, st);
+    }
+    return launch_rev_k<NBLK, DK, MODE, 4>(a, grid, st);
 }
 
 template <int NBLK>
