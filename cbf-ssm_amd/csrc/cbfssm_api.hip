@@ -70,6 +70,7 @@ struct PrepArgs {
     double* Wp;            // triangular operand images (two-triangular GP form)
     double* WTp;
     double* info_out;      // kmm_chol: 1 double
+    const double* Kin;     // cbfssm_cholesky_f64: factorise this M x M matrix instead of building K(Z, Z)
 };
 
 struct PrepArgs2 {
@@ -104,20 +105,30 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
 
     if (tid == 0) s_info = 0;
     // X / lengthscales and row norms (gp_tf.py:34-35)
-    for (int i = tid; i < M * D; i += PREP_NT) a.Zs[i] = a.Z[i] / a.ls[i % D];
-    __syncthreads();
-    for (int m = tid; m < M; m += PREP_NT) {
-        double s = 0.0;
-        for (int j = 0; j < D; ++j) s += a.Zs[m * D + j] * a.Zs[m * D + j];
-        Xs[m] = s;
+    if (!a.Kin) {
+        for (int i = tid; i < M * D; i += PREP_NT) a.Zs[i] = a.Z[i] / a.ls[i % D];
+        __syncthreads();
+        for (int m = tid; m < M; m += PREP_NT) {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s += a.Zs[m * D + j] * a.Zs[m * D + j];
+            Xs[m] = s;
+        }
     }
     __syncthreads();
-    const double var = a.var[0];
+    const double var = a.Kin ? 0.0 : a.var[0];
     constexpr int NWAVE = PREP_NT / 64;
     const int NBT = (M + 15) / 16;
     const int wv = tid >> 6, l = tid & 63, g = l >> 4, nl = l & 15;
     // X X^T in 16 x 16 tiles on the f64 MFMA units (gp_tf.py:36: the matmul of the -2 X X^T + |x|^2 + |x'|^2 expansion)
-    for (int t = wv; t < NBT * NBT; t += NWAVE) {
+    if (a.Kin) {
+        // cast_cholesky of a given matrix (gp_tf.py:52-65): the working matrix is its lower triangle + jitter on the diagonal
+        for (int idx = tid; idx < M * M; idx += PREP_NT) {
+            const int i = idx / M, k = idx - i * M;
+            const double kv = a.Kin[idx];
+            Wm[i * LD + k] = (k < i) ? kv : ((k == i) ? kv + a.jitter : 0.0);
+        }
+    }
+    for (int t = wv; t < (a.Kin ? 0 : NBT * NBT); t += NWAVE) {
         const int ib = t / NBT, kb = t - ib * NBT;
         const int ia = 16 * ib + nl, ka = 16 * kb + nl;
         d4 dot = {0, 0, 0, 0};
@@ -803,9 +814,110 @@ int cbfssm_gp_predict_f64(const cbfssm_pack_layout* L, const double* pack, const
     PredictArgs a;
     a.pk = pack_ptrs(L, pack); a.X = X; a.npts = npts; a.D = L->D; a.Do = L->Do; a.fmean = fmean; a.fvar = fvar;
     a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
+    a.a2o = nullptr;
     int rc = dispatch_predict(L->NBLK, L->DK, a, (hipStream_t)stream);
     if (rc) return fail(rc, "gp_predict launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     return 0;
+}
+
+int cbfssm_cholesky_f64(int M, const double* mat, double jitter, double* L, double* info, double* work, void* stream)
+{
+    if (M < 1 || M > CBFSSM_MAX_M) return fail(-1, "bad M");
+    if (!mat || !L || !info || !work) return fail(-1, "null pointer");
+    PrepArgs2 aa;
+    memset(&aa, 0, sizeof(aa));
+    PrepArgs& a = aa.g[0];
+    a.M = M; a.D = 1; a.jitter = jitter; a.Kin = mat;
+    a.Lout = L; a.gmat = (M > PREP_LDS_MAX_M) ? work : nullptr;
+    a.info_out = info;
+    return launch_prepare(aa, 1, M, (hipStream_t)stream);
+}
+
+namespace cbfssm {
+__global__ void rbf_k_kernel(int n, int m, int D, const double* X, const double* X2, const double* ls, const double* var,
+                             double* out)
+{
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= int64_t(n) * m) return;
+    const int i = int(idx / m), k = int(idx - int64_t(i) * m);
+    // the reference's expansion (gp_tf.py:33-43): -2 x.x' + |x|^2 + |x'|^2 on lengthscale-scaled inputs, no clamp
+    double dot = 0.0, xs = 0.0, x2s = 0.0;
+    for (int j = 0; j < D; ++j) {
+        const double a = X[int64_t(i) * D + j] / ls[j], b = X2[int64_t(k) * D + j] / ls[j];
+        dot += a * b; xs += a * a; x2s += b * b;
+    }
+    out[idx] = var[0] * exp(-0.5 * (-2.0 * dot + xs + x2s));
+}
+
+// fvar[p][d] += sum_j ( sum_m q_sqrt[d][m][j] A2[m][p] )^2   (conditional(), full-matrix q_sqrt, gp_tf.py:89-94)
+__global__ __launch_bounds__(256) void fullq_kernel(const double* a2t, const double* q, int M, int NBLK, int Do,
+                                                    int64_t npts, double* fvar)
+{
+    extern __shared__ double sh[];                    // [16 NBLK][16] A2 of this 16-point group, dense
+    __shared__ double red[256];
+    const int g = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
+    const double* t = a2t + int64_t(g) * NBLK * 256;
+    for (int i = tid; i < NBLK * 256; i += 256) {
+        const int rb = i >> 8, r = (i >> 6) & 3, l = i & 63;
+        sh[(16 * rb + (l >> 4) + 4 * r) * 16 + (l & 15)] = t[i];
+    }
+    __syncthreads();
+    const int n = tid & 15, tj = tid >> 4;
+    double acc = 0.0;
+    for (int j = tj; j < M; j += 16) {
+        double v = 0.0;
+        for (int m = 0; m < M; ++m) v += q[(int64_t(d) * M + m) * M + j] * sh[m * 16 + n];
+        acc += v * v;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tj == 0) {
+        double s = 0.0;
+        for (int k = 0; k < 16; ++k) s += red[k * 16 + n];
+        const int64_t p = int64_t(g) * 16 + n;
+        if (p < npts) fvar[p * Do + d] += s;
+    }
+}
+}  // namespace cbfssm
+
+int cbfssm_rbf_k_f64(int n, int m, int D, const double* X, const double* X2, const double* lengthscales,
+                     const double* variance, double* out, void* stream)
+{
+    if (n < 1 || m < 1 || D < 1 || D > CBFSSM_MAX_DIN) return fail(-1, "bad n/m/D");
+    if (!X || !X2 || !lengthscales || !variance || !out) return fail(-1, "null pointer");
+    const int64_t tot = int64_t(n) * m;
+    hipLaunchKernelGGL(rbf_k_kernel, dim3(unsigned((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, m, D, X, X2,
+                       lengthscales, variance, out);
+    return check_launch("rbf_k");
+}
+
+int64_t cbfssm_gp_predict_fullq_work_elems(const cbfssm_pack_layout* L, int64_t npts)
+{
+    if (!L || npts < 0) return -1;
+    return (npts + 15) / 16 * L->NBLK * 256;
+}
+
+int cbfssm_gp_predict_fullq_f64(const cbfssm_pack_layout* L, const double* pack, const double* q_sqrt, const double* X,
+                                int64_t npts, double* fmean, double* fvar, double* work, void* stream)
+{
+    if (!L || !pack || !q_sqrt || !X || !fmean || !fvar || !work) return fail(-1, "null pointer");
+    if (npts < 0 || npts > (int64_t(1) << 34)) return fail(-1, "bad npts");
+    if (npts == 0) return 0;
+    PredictArgs a;
+    a.pk = pack_ptrs(L, pack); a.X = X; a.npts = npts; a.D = L->D; a.Do = L->Do; a.fmean = fmean; a.fvar = fvar;
+    a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
+    a.a2o = work;
+    int rc = dispatch_predict(L->NBLK, L->DK, a, (hipStream_t)stream);
+    if (rc) return fail(rc, "gp_predict launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
+    const size_t lds = size_t(16) * L->NBLK * 16 * sizeof(double);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fullq_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(-int(e) - 1000, "fullq: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(fullq_kernel, dim3(unsigned((npts + 15) / 16), unsigned(L->Do)), dim3(256), lds, (hipStream_t)stream,
+                       (const double*)work, q_sqrt, L->M, L->NBLK, L->Do, npts, fvar);
+    return check_launch("gp_predict_fullq");
 }
 
 int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p)

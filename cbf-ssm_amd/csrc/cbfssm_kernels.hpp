@@ -318,6 +318,7 @@ struct PredictArgs {
     double* fmean;     // (npts, Do)
     double* fvar;
     int tri;
+    double* a2o;       // optional: the A2 = K^-1 k tiles of every 16-point group, [group][NBLK*256] in MFMA C-layout
 };
 
 // TRI: the GP conditional in the reference's own two-triangular form (gp_tf.py:137-145) instead of the K^-1 contraction:
@@ -930,8 +931,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(Pr
     double kr[RB][4];
     tile.phase1(xq, Kt, kr, w, l);
     __syncthreads();
-    if constexpr (TRI) tile.phase2_tri(Kt, At, flag, 1, part, w, l);
-    else tile.phase2(Kt, part, kr, w, l);
+    double* a2o = a.a2o ? a.a2o + int64_t(blockIdx.x) * (NBLK * 256) : nullptr;
+    if constexpr (TRI) tile.phase2_tri(Kt, At, flag, 1, part, w, l, a2o);
+    else tile.phase2(Kt, part, kr, w, l, a2o);
     __syncthreads();
 #pragma unroll
     for (int qi = 0; qi < TT::QPW; ++qi) {

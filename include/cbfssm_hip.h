@@ -128,6 +128,25 @@ int cbfssm_gp_predict_f64(const cbfssm_pack_layout* layout, const double* pack, 
                           double* fmean, double* fvar, void* stream);
 
 /*
+ * The remaining pieces of gp_tf.py as stand-alone calls (none of them is on a time loop):
+ *   cbfssm_cholesky_f64      cast_cholesky / _jitter_cholesky of a GIVEN matrix (gp_tf.py:52-65): mat (M,M) symmetric ->
+ *                            L (M,M) lower with mat + jitter I = L L^T, info (1 double: 0 or the failing leading minor);
+ *                            work: >= M*(M+1) doubles.  The blocked MFMA factorisation of cbfssm_gp_prepare_f64.
+ *   cbfssm_rbf_k_f64         RBF.K(X, X2) (gp_tf.py:33-49): X (n,D), X2 (m,D) -> out (n,m).
+ *   cbfssm_gp_predict_fullq_f64   conditional() with a full-matrix q_sqrt (gp_tf.py:68-100, the q_sqrt.ndims == 3 branch):
+ *                            the pack is prepared with f as zeta_mean and zeta_var = 0; q_sqrt (Do,M,M) lower triangular
+ *                            per output dimension; fvar += sum_j (q_sqrt[d]^T A2)_j^2.  work: cbfssm_gp_predict_fullq_work_elems
+ *                            doubles (the A2 tiles).  (The q_sqrt.ndims == 2 branch IS cbfssm_gp_predict_f64 with
+ *                            zeta_var = q_sqrt^2; q_sqrt = None is zeta_var = 0.)
+ */
+int cbfssm_cholesky_f64(int M, const double* mat, double jitter, double* L, double* info, double* work, void* stream);
+int cbfssm_rbf_k_f64(int n, int m, int D, const double* X, const double* X2, const double* lengthscales,
+                     const double* variance, double* out, void* stream);
+int64_t cbfssm_gp_predict_fullq_work_elems(const cbfssm_pack_layout* layout, int64_t npts);
+int cbfssm_gp_predict_fullq_f64(const cbfssm_pack_layout* layout, const double* pack, const double* q_sqrt, const double* X,
+                                int64_t npts, double* fmean, double* fvar, double* work, void* stream);
+
+/*
  * Both backward (recognition) runs, CBFSSM._backward/_backward_run/_backward_body (cbfssm.py:84-158).
  *   u (B,T,dim_u), y (B,T,dim_y), hid_b (2,T,N), eps_b (2,T,N), var_x (dim_x)
  *   -> y2 (T,N,dim_x-dim_y)  [every t written by exactly one run, cbfssm.py:123-128,151]

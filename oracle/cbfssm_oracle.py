@@ -72,6 +72,29 @@ def cast_cholesky(mat, jitter=JITTER):
     return np.linalg.cholesky(mat)
 
 
+
+def conditional(Xnew, X, kern, f, q_sqrt, Lm=None):
+    """gp_tf.py:68-100: the GPflow-1.0-style conditional with q_sqrt None, (M, Do) or (Do, M, M)."""
+    num_func = f.shape[1]                                                              # :70
+    Kmn = kern.K(X, Xnew)                                                              # :71
+    if Lm is None:
+        Lm = cast_cholesky(kern.K(X), jitter=1e-8)                                     # :72-73
+    A = sla.solve_triangular(Lm, Kmn, lower=True)                                      # :76
+    fvar = kern.Kdiag(Xnew) - np.sum(np.square(A), 0)                                  # :79
+    fvar = np.tile(fvar[None, :], (num_func, 1))                                       # :80-81
+    A = sla.solve_triangular(Lm.T, A, lower=False)                                     # :84
+    fmean = A.T @ f                                                                    # :87
+    if q_sqrt is not None:
+        if q_sqrt.ndim == 2:
+            LTA = A[None, :, :] * q_sqrt.T[:, :, None]                                 # :91
+        elif q_sqrt.ndim == 3:
+            A_tiled = np.tile(A[None, :, :], (num_func, 1, 1))                         # :93
+            LTA = np.matmul(np.transpose(q_sqrt, (0, 2, 1)), A_tiled)                  # :94
+        else:
+            raise ValueError("bad dimension for q_sqrt")
+        fvar = fvar + np.sum(np.square(LTA), 1)                                        # :98
+    return fmean, fvar.T                                                               # :100
+
 class GPModel:
     """gp_tf.py:103-172 with the trainable tensors passed in instead of drawn (gp_tf.py:112-123)."""
 
