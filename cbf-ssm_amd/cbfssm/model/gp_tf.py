@@ -64,9 +64,9 @@ class RBF:
         X2 = X if X2 is None else _f64(X2, self.device)
         assert X.dim() == 2 and X2.dim() == 2 and X.shape[1] == X2.shape[1] == self.lengthscales.numel()
         out = torch.empty(X.shape[0], X2.shape[0], dtype=torch.float64, device=self.device)
-        rc = _l.load().cbfssm_rbf_k_f64(X.shape[0], X2.shape[0], X.shape[1], _ptr(X), _ptr(X2),
-                                        _ptr(self.lengthscales.contiguous()), _ptr(self.variance.contiguous()), _ptr(out),
-                                        _stream())
+        ls, var = self.lengthscales.contiguous(), self.variance.contiguous()     # (named: they must outlive the launch)
+        rc = _l.load().cbfssm_rbf_k_f64(X.shape[0], X2.shape[0], X.shape[1], _ptr(X), _ptr(X2), _ptr(ls), _ptr(var),
+                                        _ptr(out), _stream())
         _l.check(rc, 'cbfssm_rbf_k_f64')
         return out
 
@@ -112,7 +112,7 @@ def conditional(Xnew, X, kern, f, q_sqrt, Lm=None):
     if q_sqrt is None:
         pack = _pack_for(kern, X, f, torch.zeros(M, Do, dtype=torch.float64, device=dev))
         return pack.predict(Xnew)
-    q = _f64(q_sqrt, dev)
+    q = _f64(q_sqrt, dev).contiguous()
     if q.dim() == 2:
         assert q.shape == (M, Do)
         return _pack_for(kern, X, f, q * q).predict(Xnew)
@@ -125,7 +125,7 @@ def conditional(Xnew, X, kern, f, q_sqrt, Lm=None):
     fmean = torch.empty(n, Do, dtype=torch.float64, device=dev)
     fvar = torch.empty_like(fmean)
     work = torch.empty(int(lib.cbfssm_gp_predict_fullq_work_elems(C.byref(pack.layout), n)), dtype=torch.float64, device=dev)
-    rc = lib.cbfssm_gp_predict_fullq_f64(C.byref(pack.layout), _ptr(pack.buf), _ptr(q.contiguous()), _ptr(Xnew), n,
+    rc = lib.cbfssm_gp_predict_fullq_f64(C.byref(pack.layout), _ptr(pack.buf), _ptr(q), _ptr(Xnew), n,
                                          _ptr(fmean), _ptr(fvar), _ptr(work), _stream())
     _l.check(rc, 'cbfssm_gp_predict_fullq_f64')
     return fmean, fvar
