@@ -201,3 +201,28 @@ def test_gp_predict_near_inducing_points(M, D, Do, ls, spread):
     _report('gp_near/M%d_ls%g_s%g' % (M, ls, spread), {'cond': cond, 'fmean': e_m, 'fvar': e_v,
                                                       'gp_form': pack.gp_form() if hasattr(pack, 'gp_form') else 'dense'})
     assert e_m <= BOUND and e_v <= BOUND, (cond, e_m, e_v)
+
+
+@pytest.mark.parametrize('ls_mult', [16, 64])
+def test_trained_like_gradient_full_recurrence(ls_mult):
+    """The adjoint on ill-conditioned K_mm (two-triangular forward form chosen automatically, dense K^-1-adjoint
+    accumulation fed by its saved A2 tiles) against reverse-mode autodiff of the float64 restatement through the
+    reference's two triangular solves, full C3 recurrence."""
+    from oracle import cbfssm_torch_ref as tref
+    w = dataclasses.replace(syn.WORKLOADS['C3'], B=2)
+    cfg = w.model_config()
+    p = syn.trained_like_params(w, ls_mult=float(ls_mult), zeta_mean=0.1)
+    u, y = syn.make_inputs(w, seed=0)
+    noise = syn.make_noise(w, seed=2)
+    scal, gref = tref.loss_and_grads(cfg, p, u, y, noise, True)
+    eng = train.HipElboGrad(cfg, DEV)
+    loss, grads, terms = eng.loss_and_grads({k: torch.tensor(v, device=DEV) for k, v in p.items()}, u, y, noise)
+    assert float(terms['info']) == 0.0
+    e = {'loss': _rel_scalar(loss, scal['loss'])}
+    for k in train.PARAM_NAMES:
+        e[k] = _rel_max(grads[k].cpu().numpy(), gref[k])
+    print('\nC3 (B=2, T=250) lengthscales x%d gradient (form %s): ' % (ls_mult, eng.pack_f.gp_form()) +
+          ' '.join('%s %.1e' % kv for kv in sorted(e.items())))
+    _report('sweep_C3_grad/ls_x%d' % ls_mult, e)
+    assert e['loss'] <= 1e-7
+    assert max(e.values()) <= 1e-4, e          # relative to the largest entry of each tensor

@@ -118,3 +118,44 @@ def test_model_surface_without_gpu():
     bad['var_x'] = np.zeros(w.dim_x)
     with pytest.raises(AssertionError):
         CBFSSM(bad)          # tf_transform.backward asserts positivity (tf_transform.py:14)
+
+
+def test_every_file_loader_reads_its_reference_format(tmp_path, monkeypatch):
+    """One synthetic file per dataset class in the format the reference's loaders read (datasets/prssm/
+    real_world_tasks.py:99-256: keys, columns, split points, Sarcos' 674-sample experiments downsampled by two;
+    datasets/ds_manager.py:11-23 + dsmanager_ds.py:11-63: ds_u / ds_x / ds_y, split 25000 / 5000, y cropped to its
+    first column for SpringNonlinear): shapes and splits of the loaded arrays."""
+    import scipy.io
+    from cbfssm.datasets import (Actuator, Ballbeam, Drive, Dryer, Furnace, Sarcos, RoboMove, RoboMoveSimple,
+                                 SpringNonlinear)
+    rng = np.random.default_rng(0)
+    d = tmp_path
+    scipy.io.savemat(str(d / 'actuator.mat'), {'u': rng.standard_normal((1024, 1)), 'p': rng.standard_normal((1024, 1))})
+    scipy.io.savemat(str(d / 'drive.mat'), {'u1': rng.standard_normal((500, 1)), 'z1': rng.standard_normal((500, 1))})
+    np.savetxt(str(d / 'ballbeam.dat'), rng.standard_normal((1000, 2)))
+    np.savetxt(str(d / 'dryer.dat'), rng.standard_normal((1000, 2)))
+    np.savetxt(str(d / 'gas_furnace.csv'), rng.standard_normal((296, 2)), delimiter=',', header='u,y', comments='')
+    sarcos = rng.standard_normal((66 * 674, 28))
+    scipy.io.savemat(str(d / 'sarcos_inv.mat'), {'sarcos_inv': sarcos})
+    for name, n, dy in (('robomove.mat', 30000, 2), ('robomove_simple.mat', 30000, 4), ('spring_nonlinear.mat', 6000, 2)):
+        scipy.io.savemat(str(d / name), {'title': 'synthetic', 'ds_u': rng.standard_normal((n, 2 if 'robo' in name else 1)),
+                                         'ds_x': rng.standard_normal((n, 3)), 'ds_y': rng.standard_normal((n, dy))})
+    monkeypatch.setenv('CBFSSM_DATA_DIR', str(d))
+    expect = {Actuator: (512, 512), Drive: (250, 250), Ballbeam: (500, 500), Dryer: (500, 500), Furnace: (148, 148)}
+    for cls, (n_tr, n_te) in expect.items():
+        ds = cls(20, 5)
+        assert (cls.dim_u, cls.dim_y) == (1, 1)
+        assert ds.train_in.shape == (1, n_tr, 1) and ds.train_out.shape == (1, n_tr, 1), cls.__name__
+        assert ds.test_in.shape == (1, n_te, 1) and ds.test_out.shape == (1, n_te, 1), cls.__name__
+        np.testing.assert_allclose(ds.train_in.reshape(-1, 1).mean(0), 0, atol=1e-12)       # z-normalised on the train split
+        np.testing.assert_allclose(ds.train_out.reshape(-1, 1).std(0), 1, atol=1e-12)
+    ds = Sarcos(100, 50)
+    assert ds.train_in.shape == (60, 337, 7) and ds.test_in.shape == (6, 337, 7) and ds.train_out.shape == (60, 337, 7)
+    # experiment 3, every second sample, torques = columns 21..27, positions = columns 0..6
+    np.testing.assert_allclose(ds.denormalize(ds.train_in[3], 'in'), sarcos[3 * 674:4 * 674:2, 21:28], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ds.denormalize(ds.test_out[0], 'out'), sarcos[60 * 674:61 * 674:2, 0:7], rtol=1e-12, atol=1e-12)
+    for cls, (du, dy, split, n) in {RoboMove: (2, 2, 25000, 30000), RoboMoveSimple: (2, 4, 25000, 30000),
+                                    SpringNonlinear: (1, 1, 5000, 6000)}.items():
+        ds = cls(50, 25)
+        assert (cls.dim_u, cls.dim_y) == (du, dy)
+        assert ds.train_in.shape == (1, split, du) and ds.test_out.shape == (1, n - split, dy), cls.__name__
