@@ -135,6 +135,9 @@ def main():
     ap.add_argument('--mode', default='auto', choices=['auto', 'eval', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline', default='sample', choices=['sample', 'full'])
+    ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'],
+                    help='float32: the float32-arithmetic forward evaluation (eval mode only; NOT the headline: the '
+                         'reference computes in float64)')
     args = ap.parse_args()
 
     from cbfssm import synthetic as syn
@@ -172,6 +175,8 @@ def main():
         have_train = False
     if mode == 'auto':
         mode = 'train' if have_train else 'eval'
+    if args.dtype == 'float32':
+        assert mode == 'eval' and world == 1, 'float32 arithmetic: forward evaluation on one GPU (--mode eval)'
 
     # ---- synthetic inputs, resident in HBM before the timed region
     g = torch.Generator(device=dev)
@@ -199,7 +204,7 @@ def main():
             return stepper.step(u, y, draw_noise(), condition=True)
     else:
         from cbfssm.hip.train import HipElboGrad
-        eng = HipElboGrad(cfg, dev, dist if world > 1 else None, require_adjoint=False)
+        eng = HipElboGrad(cfg, dev, dist if world > 1 else None, require_adjoint=False, dtype=args.dtype)
         out8 = torch.zeros(8, dtype=torch.float64, device=dev)
 
         def step():
@@ -231,7 +236,10 @@ def main():
 
     # ---- per-kernel timing of the time-loop kernels with HIP events on the launch stream
     roof = None
-    if rank == 0:
+    if rank == 0 and args.dtype == 'float32':
+        roof = {'bound': 'mfma', 'achieved': None, 'peak': None, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None,
+                'note': 'float32-arithmetic forward evaluation: whole-step time only'}
+    elif rank == 0:
         import ctypes as C
         l = lib.load()
         st = ops._stream()
@@ -345,7 +353,8 @@ def main():
             'metric': 'ELBO steps/sec', 'value': steps_per_s * world, 'unit': 'steps/s (one step = one %d-sequence '
                       'mini-batch per GPU)' % w.B,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64' if args.dtype == 'float64' else 'f32',
+            'data': 'synthetic',
             'states_per_sec': steps_per_s * world * w.B * w.T,
             'config': {'workload': '%s %s step: M=%d T=%d B=%d/GPU S=%d dim_x=%d dim_u=%d dim_y=%d recog_len=%d'
                                    % (w.name, mode, w.M, w.T, w.B, w.S, w.dim_x, w.dim_u, w.dim_y, w.recog_len),
@@ -354,7 +363,7 @@ def main():
             'loss': loss,
             'roofline': roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.dtype == 'float64':
             rec['cpu_baseline'] = cpu_baseline(w, mode, full=(args.cpu_baseline == 'full'))
             rec['speedup_vs_cpu_baseline'] = rec['value'] / rec['cpu_baseline']['value']
         else:
