@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CBFSSM_HIP_LIB') or os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libcbfssm_hip.so'))
 
-SCAL_SIGMA2, SCAL_LOGDET, SCAL_KLZ, SCAL_INFO, SCAL_COND, SCAL_COUNT = 0, 1, 2, 3, 4, 16
+SCAL_SIGMA2, SCAL_LOGDET, SCAL_KLZ, SCAL_INFO, SCAL_COND, SCAL_JITTER, SCAL_COUNT = 0, 1, 2, 3, 4, 5, 16
 GP_FORM_DENSE, GP_FORM_TRI = 0, 1
 JITTER = 1e-8   # cbfssm/model/gp_tf.py:57
 

@@ -580,13 +580,23 @@ class HipElboGrad:
         gs2 = gs2 + 0.5 * (torch.diagonal(Kkl)[:, None] - 1.0 / zvar)
         gB_kl = 0.5 * (torch.diag(zvar.sum(1)) + zmean @ zmean.T)
         # K^-1 = (K_mm + jitter I)^-1 ; log det term of the KL: d/dK (0.5 Do log det K) = 0.5 Do K^-1
+        jit = pack.scal[_l.SCAL_JITTER]
         if kl_pack is None:
-            gK = -(Kinv @ (gB + gB_kl) @ Kinv) + 0.5 * Do * Kinv
+            T = Kinv @ (gB + gB_kl)
+            TK = T @ Kinv
+            gK = -TK + 0.5 * Do * Kinv
+            # tr(Kbar K_mm) with K^-1 K_mm = I - jitter K^-1: the terms are of order cond |G|, where the entry sum of
+            # Kbar o K_mm cancels numbers of order cond^2 |G| (it decides d loss / d sigma^2 on an ill-conditioned K_mm)
+            tr_gKK = -torch.trace(T) + jit * torch.trace(TK) + 0.5 * Do * (M - jit * torch.trace(Kinv))
         else:
-            gK = -(Kinv @ gB @ Kinv) - (Kkl @ gB_kl @ Kkl) + 0.5 * Do * Kkl
+            T = Kinv @ gB
+            TK = T @ Kinv
+            gK = -TK - (Kkl @ gB_kl @ Kkl) + 0.5 * Do * Kkl
+            # (the prior's K_kl^-1 is jitter free: K_kl^-1 K_mm = I)
+            tr_gKK = -torch.trace(T) + jit * torch.trace(TK) - (Kkl * gB_kl.T).sum() + 0.5 * Do * M
         # K = var * exp(-0.5 d2(z~))                                           (gp_tf.py:33-49)
         gKK = gK * Kmm
-        gvar = gKK.sum() / var[0] + gsig + glogsig / var[0]
+        gvar = tr_gKK / var[0] + gsig + glogsig / var[0]
         Wd = -0.5 * gKK
         Ws = Wd + Wd.T
         gZt = gZt + 2.0 * (Ws.sum(1)[:, None] * Zs - Ws @ Zs)

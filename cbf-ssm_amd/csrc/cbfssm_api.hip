@@ -406,6 +406,7 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
         double c0 = 0.0, c1 = 0.0;
         for (int i = 0; i < NWAVE; ++i) { c0 = fmax(c0, cn[0][i]); c1 = fmax(c1, cn[1][i]); }
         a.scal[CBFSSM_SCAL_COND] = c0 * c1;
+        a.scal[CBFSSM_SCAL_JITTER] = a.jitter;
 #ifdef CBF_PREP_STAMPS
         a.scal[8] = double(tk_pan); a.scal[9] = double(tk_upd); a.scal[10] = double(tk2 - tk1); a.scal[11] = double(clock64() - tk2);
         // (scal[8..11]: cycles in panels, rank updates, outputs + K^-1 = G G^T, operand images + KL; Kmm build = rest)

@@ -24,6 +24,8 @@ struct GpTail {
     const double* Zs;         // [M][D]   z / lengthscale
     double* T;                // scratch [M][max(M,48)]: Kinv G, then WZ [M][D] and K^-1 mu [M][Do]
     double* G2;               // scratch [M][M]
+    double* dv;               // scratch [M]: per-row terms of sum(Kbar o K_mm) in the form that does not cancel (tail_gemm<1>)
+    const double* scal;       // the pack's scalar block (jitter)
     const double* zmean;      // [M][Do]
     const double* zvar;       // [M][Do]  constrained
     const double* ls;         // [D]      constrained
@@ -139,6 +141,14 @@ __global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
         else {
             const double kinv = p.Kinv[int64_t(i) * M + j];
             p.G2[int64_t(i) * M + j] = (-acc + 0.5 * p.Do * kinv) * p.Kmm[int64_t(i) * M + j];
+            // d loss / d sigma^2 needs sum_ij Kbar_ij K_mm,ij = tr(Kbar K_mm).  Summing the entries of G2 cancels twice
+            // (entries of K^-1 G K^-1 are of order cond^2 |G|): with K^-1 K_mm = I - jitter K^-1 the same trace is
+            //     -tr(T) + jitter tr(T K^-1) + 0.5 Do (M - jitter tr K^-1),
+            // whose terms are of order cond |G| only (measured on a trained-like K_mm with cond 3e7: 3.5e-2 -> see DESIGN).
+            if (i == j) {
+                const double jit = p.scal[CBFSSM_SCAL_JITTER];
+                p.dv[i] = -p.T[int64_t(i) * M + i] + jit * acc + 0.5 * p.Do * (1.0 - jit * kinv);
+            }
         }
     }
 }
@@ -163,15 +173,12 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
     const int wv = tid >> 6, l = tid & 63;
     double tot = 0.0;
     for (int i = wv; i < M; i += NT / 64) {              // one wave per row: lanes over the columns
-        double s = 0.0, t1 = 0.0;
-        for (int j = l; j < M; j += 64) {
-            const double gij = G2[int64_t(i) * M + j];
-            s += gij + G2[int64_t(j) * M + i];
-            t1 += gij;
-        }
-        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); t1 += __shfl_xor(t1, o); }
-        if (l == 0) { wsrow[i] = -0.5 * s; tot += t1; }
+        double s = 0.0;
+        for (int j = l; j < M; j += 64) s += G2[int64_t(i) * M + j] + G2[int64_t(j) * M + i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (l == 0) wsrow[i] = -0.5 * s;
     }
+    for (int i = tid; i < M; i += NT) tot += p.dv[i];    // tr(Kbar K_mm), per-row terms from tail_gemm<1>
     tot = block_sum_t(tot, red, tid, NT);
     __syncthreads();
 
@@ -317,7 +324,9 @@ int cbfssm_constrain_f64(const cbfssm_param_layout* pl, const double* pflat, dou
 int64_t cbfssm_train_tail_work_elems(const cbfssm_pack_layout* Lf, const cbfssm_pack_layout* Lb)
 {
     if (!Lf || !Lb) return -1;
-    auto one = [](const cbfssm_pack_layout* L) { return int64_t(L->M) * (L->M > 48 ? L->M : 48) + int64_t(L->M) * L->M; };
+    auto one = [](const cbfssm_pack_layout* L) {
+        return int64_t(L->M) * (L->M > 48 ? L->M : 48) + int64_t(L->M) * L->M + (int64_t(L->M) + 63) / 64 * 64;
+    };
     return one(Lf) + one(Lb);
 }
 
@@ -349,6 +358,8 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
         p.Kinv = pack[g] + L[g]->Kinv; p.Kmm = pack[g] + L[g]->Kmm; p.Zs = pack[g] + L[g]->Zs;
         p.T = w; w += int64_t(M) * (M > 48 ? M : 48);
         p.G2 = w; w += int64_t(M) * M;
+        p.dv = w; w += (int64_t(M) + 63) / 64 * 64;
+        p.scal = pack[g] + L[g]->scal;
         const int64_t* off = pl->off + 5 * g;
         p.zmean = cflat + off[1]; p.zvar = cflat + off[2]; p.var = cflat + off[3]; p.ls = cflat + off[4];
         p.zvar_unc = pflat + off[2]; p.var_unc = pflat + off[3]; p.ls_unc = pflat + off[4];

@@ -35,6 +35,7 @@ enum {
     CBFSSM_SCAL_KLZ = 2,     /* prior_kl() */
     CBFSSM_SCAL_INFO = 3,    /* 0 = OK, k>0 = leading minor k not positive definite */
     CBFSSM_SCAL_COND = 4,    /* infinity-norm condition number of K_mm + jitter I: |K|_inf |K^-1|_inf */
+    CBFSSM_SCAL_JITTER = 5,  /* the jitter this pack was prepared with */
     CBFSSM_SCAL_COUNT = 16
 };
 
