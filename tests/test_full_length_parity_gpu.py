@@ -203,13 +203,16 @@ def test_gp_predict_near_inducing_points(M, D, Do, ls, spread):
     assert e_m <= BOUND and e_v <= BOUND, (cond, e_m, e_v)
 
 
-@pytest.mark.parametrize('ls_mult', [16, 64])
-def test_trained_like_gradient_full_recurrence(ls_mult):
+@pytest.mark.parametrize('ls_mult,base,T', [(16, 'C3', 250), (64, 'C3', 250), (32, 'C4', 60)])
+def test_trained_like_gradient_full_recurrence(ls_mult, base, T):
     """The adjoint on ill-conditioned K_mm (two-triangular forward form chosen automatically, dense K^-1-adjoint
     accumulation fed by its saved A2 tiles) against reverse-mode autodiff of the float64 restatement through the
-    reference's two triangular solves, full C3 recurrence."""
+    reference's two triangular solves, full C3 recurrence (and the stash-mode adjoint of the C4 tile at T = 60).  The
+    kernel-variance entry is the sensitive one: d loss / d sigma^2 = tr(Kbar K_mm) / sigma^2 + ..., and the entry sum of
+    Kbar o K_mm cancels numbers of order cond^2 (3.5e-2 off at cond 3e7 before the train tail used
+    tr(Kbar K_mm) = -tr(T) + jitter tr(T K^-1) + 0.5 Do (M - jitter tr K^-1), csrc/cbfssm_tail.hip)."""
     from oracle import cbfssm_torch_ref as tref
-    w = dataclasses.replace(syn.WORKLOADS['C3'], B=2)
+    w = dataclasses.replace(syn.WORKLOADS[base], B=2, T=T)
     cfg = w.model_config()
     p = syn.trained_like_params(w, ls_mult=float(ls_mult), zeta_mean=0.1)
     u, y = syn.make_inputs(w, seed=0)
@@ -221,8 +224,8 @@ def test_trained_like_gradient_full_recurrence(ls_mult):
     e = {'loss': _rel_scalar(loss, scal['loss'])}
     for k in train.PARAM_NAMES:
         e[k] = _rel_max(grads[k].cpu().numpy(), gref[k])
-    print('\nC3 (B=2, T=250) lengthscales x%d gradient (form %s): ' % (ls_mult, eng.pack_f.gp_form()) +
+    print('\n%s (B=2, T=%d) lengthscales x%d gradient (form %s): ' % (base, T, ls_mult, eng.pack_f.gp_form()) +
           ' '.join('%s %.1e' % kv for kv in sorted(e.items())))
-    _report('sweep_C3_grad/ls_x%d' % ls_mult, e)
+    _report('sweep_%s_grad/ls_x%d' % (base, ls_mult), e)
     assert e['loss'] <= 1e-7
     assert max(e.values()) <= 1e-4, e          # relative to the largest entry of each tensor
