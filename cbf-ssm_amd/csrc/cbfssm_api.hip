@@ -667,9 +667,11 @@ static int pass_nc(const cbfssm_problem* p, int mode)
     }
     if (p->M > 112) return 1;   // (the skewed kernel's two tiles do not fit; the shared-operand variant 3 equals the
                                 //  hand-scheduled one-block kernel at C4: 6.96 vs 6.95 ms, so it stays opt-in)
-    // measured at C3: the skewed two-group kernel is 3 % faster on the many-workgroup backward runs and 2 % slower
-    // on the forward pass (320 -> 160 workgroups)
-    if (mode == MODE_BWD) return n >= 32 * 128 ? 2 : 1;
+    // measured at C3 (round 1): the skewed two-group kernel 3 % faster on the many-workgroup backward runs, 2 % slower on
+    // the forward pass (320 -> 160 workgroups).  Round 2, with the compile-time trim of the all-padding k-steps: the
+    // one-group kernel is the faster one on the backward runs too (2.26 vs 2.34 ms), so the skewed kernel is opt-in
+    // (CBFSSM_NC_BWD=2).
+    (void)n;
     return 1;   // (also required by half mode: only the one-group kernel knows x0)
 }
 

@@ -201,7 +201,7 @@ static int contract_split(int64_t nslots)
     if (n > 256) n = 256;
     if (n >= 8) n &= ~int64_t(7);
     if (n < 1) n = 1;
-    if (const char* e = getenv("CBFSSM_CONTRACT_SPLIT")) {          // measurement switch (DESIGN.md section 3.6)
+    if (const char* e = getenv("CBFSSM_CONTRACT_SPLIT")) {          // measurement switch (DESIGN.md section 3.7)
         const long v = atol(e);
         if (v >= 1 && v <= nslots) n = v;
     }
