@@ -170,3 +170,25 @@ def test_shared_operand_pass_variant_matches_oracle(kw, monkeypatch):
     assert abs(float(loss) - scal['loss']) <= 1e-9 * abs(scal['loss'])
     for k in train.PARAM_NAMES:
         np.testing.assert_allclose(grads[k].cpu().numpy(), gref[k], rtol=1e-6, atol=1e-7 * np.abs(gref[k]).max())
+
+
+@pytest.mark.parametrize('kw', [
+    dict(M=100, dim_x=14, dim_u=7, dim_y=7, T=20, B=3, S=20, recog_len=4, k_factor=50., var_y=0.05 ** 2),   # Sarcos tile, 4 blocks
+    dict(M=20, dim_x=4, dim_u=1, dim_y=1, T=23, B=3, S=11, recog_len=5, k_factor=100.),                     # 3 blocks: odd count
+])
+def test_skewed_pass_variant_matches_oracle(kw, monkeypatch):
+    """pass_kernel_skew (two column blocks half a step apart; opt-in since round 2) forced on, against the oracle."""
+    monkeypatch.setenv('CBFSSM_NC_FWD', '2')
+    monkeypatch.setenv('CBFSSM_NC_BWD', '2')
+    monkeypatch.setenv('CBFSSM_GP_FORM', 'dense')
+    orc = _oracle()
+    w = syn.tiny(loss_factors=(2., 0.4), **kw)
+    cfg = w.model_config()
+    p = syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)
+    u, y = syn.make_inputs(w, seed=0)
+    noise = syn.make_noise(w, seed=2)
+    ref = orc.elbo_step(cfg, p, u, y, noise, True)
+    eng = ops.HipElbo(cfg, DEV)
+    eng.prepare(p)
+    ws = eng.run(u, y, noise, condition=True)
+    _compare(ws, w, ref)
