@@ -139,7 +139,8 @@ def _floor(cfg, p, u, y, noise, ref):
             'pred_var': _rel_elem(o['pred_var'].numpy(), ref['pred_var'])}
 
 
-SWEEP = [8, 16, 32, 64, 128, 256]       # lengthscale multipliers -> cond(K_mm + 1e-8 I) 5e3, 1e5, 2e6, 3e7, 4e8, 2e9
+SWEEP = [8, 32, 128, 256]       # lengthscale multipliers -> cond(K_mm + 1e-8 I) 5e3, 2e6, 4e8, 2e9 (x16 -> 1e5 and x64 ->
+                                # 3e7 were run too: DESIGN.md section 5 has all six rows; four keep the suite short)
 
 
 @pytest.mark.parametrize('ls_mult', SWEEP)
@@ -203,7 +204,7 @@ def test_gp_predict_near_inducing_points(M, D, Do, ls, spread):
     assert e_m <= BOUND and e_v <= BOUND, (cond, e_m, e_v)
 
 
-@pytest.mark.parametrize('ls_mult,base,T', [(16, 'C3', 250), (64, 'C3', 250), (32, 'C4', 60)])
+@pytest.mark.parametrize('ls_mult,base,T', [(64, 'C3', 250), (32, 'C4', 60)])      # (x16 at C3: 7e-10)
 def test_trained_like_gradient_full_recurrence(ls_mult, base, T):
     """The adjoint on ill-conditioned K_mm (two-triangular forward form chosen automatically, dense K^-1-adjoint
     accumulation fed by its saved A2 tiles) against reverse-mode autodiff of the float64 restatement through the
