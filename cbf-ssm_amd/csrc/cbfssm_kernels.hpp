@@ -270,12 +270,19 @@ __device__ __forceinline__ void flag_release(int* f, int v)
 {
     __hip_atomic_store((lds_int*)f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void flag_wait(int* f, int v)
+// A poll that runs out (never in a correct launch: the bound only keeps a broken one from hanging) raises the marker in
+// slot 96 of the flag array; the pass kernel turns it into a NaN partial sum, so a broken hand-off shows up as a NaN loss
+// instead of a silently wrong one.
+#define CBF_FLAG_TIMEOUT_SLOT 96
+__device__ __forceinline__ void flag_wait(int* flags, int idx, int v)
 {
     int spins = 0;
-    while (__hip_atomic_load((lds_int*)f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+    while (__hip_atomic_load((lds_int*)(flags + idx), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) break;          // never reached in a correct launch; keeps a broken one from hanging
+        if (++spins > (1 << 22)) {
+            __hip_atomic_store((lds_int*)(flags + CBF_FLAG_TIMEOUT_SLOT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
     }
 }
 
@@ -525,7 +532,7 @@ struct Tile {
 #pragma unroll
         for (int kb = RBI + 1; kb < NBLK; ++kb) {
             if (4 * kb < KSE) {
-                flag_wait(flag + kb, epoch);
+                flag_wait(flag, kb, epoch);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int s = 4 * kb + r;
@@ -603,7 +610,7 @@ struct Tile {
                 for (int j = 0; j < 4; ++j) aop[i][j] = WTp[(rb * KS + 4 * kb + j) * 64 + l];
             }
             const int pw = kb / RB;
-            if (pw != w) flag_wait(flag + pw, epoch);
+            if (pw != w) flag_wait(flag, pw, epoch);
             double b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = At[64 * (4 * kb + j) + l];
@@ -925,7 +932,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict_kernel(Pr
         xq[i] = v;
     }
     if constexpr (TRI) {
-        if (tid < 64) flag[tid] = 0;
+        if (tid < 64) { flag[tid] = 0; flag[tid + 64] = 0; }
     }
     __syncthreads();
     double kr[RB][4];
@@ -1073,7 +1080,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
     // xq rows [0,Do) carry the chain state, rows [Do,D) the auxiliary inputs, rows [D,4*DK) stay zero
     for (int i = tid; i < NC * XS; i += NT) xq[i] = 0.0;
     if constexpr (TRI) {
-        if (tid < 64) flag[tid] = 0;
+        if (tid < 64) { flag[tid] = 0; flag[tid + 64] = 0; }
     }
     __syncthreads();
     const bool resample0 = (MODE == MODE_BWD) && (((t_first + 1 + run * R) % P) == 0);
@@ -1238,7 +1245,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
             else v += 0.5 * (lin[qi] * 2.8378770664093453391 + lp[qi].log());          // log(2 pi e)
         }
     }
-    const double tot = block_sum(v, red, tid, NT);
+    double tot = block_sum(v, red, tid, NT);
+    if constexpr (TRI) {
+        if (tid == 0 && flag[CBF_FLAG_TIMEOUT_SLOT] != 0) tot = __builtin_nan("");   // a hand-off poll ran out (see flag_wait)
+    }
     if (tid == 0) {   // partial sums are indexed per 16-chain group, whatever the kernel variant
         const int G16p = (a.N + 15) >> 4;
         for (int cq = 0; cq < NC; ++cq)
