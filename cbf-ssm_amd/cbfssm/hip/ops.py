@@ -128,15 +128,16 @@ class GPPack:
     def Kinv(self):
         return self.section('Kinv', (self.M, self.M))
 
-    def pack_f32(self):
+    def pack_f32(self, bf16=False):
         """float32 MFMA images of this pack for the float32-arithmetic passes (cbfssm_gp_pack_f32): the Cholesky and K^-1
-        were computed in float64 and are cast here, as the reference does for float32 models (gp_tf.py:57-65)."""
+        were computed in float64 and are cast here, as the reference does for float32 models (gp_tf.py:57-65).
+        bf16=True: the K^-1 operand rounded to bfloat16 (cbfssm_gp_pack_bf16; the passes then round the kernel tile too)."""
         lib = _l.load()
         if getattr(self, 'buf32', None) is None:
             n = int(lib.cbfssm_pack_f32_elems(C.byref(self.layout)))
             self.buf32 = torch.zeros(n, dtype=torch.float32, device=self.buf.device)
-        _l.check(lib.cbfssm_gp_pack_f32(C.byref(self.layout), _ptr(self.buf), C.c_void_p(self.buf32.data_ptr()), _stream()),
-                 'cbfssm_gp_pack_f32')
+        fn = lib.cbfssm_gp_pack_bf16 if bf16 else lib.cbfssm_gp_pack_f32
+        _l.check(fn(C.byref(self.layout), _ptr(self.buf), C.c_void_p(self.buf32.data_ptr()), _stream()), 'cbfssm_gp_pack_f32')
         return self.buf32
 
     def predict_f32(self, X):
@@ -300,7 +301,7 @@ class ElboWorkspace:
 
 
 def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, loss_factors, ws=None,
-                 keep_h=False, f32=False):
+                 keep_h=False, f32=False, bf16=False):
     """One forward evaluation of the ELBO (cbfssm.py:84-271) from prepared GP packs.  Asynchronous.
 
     Returns the workspace; ws.out = [loglik, kl_x, entropy, kl_z_f, kl_z_b, elbo, loss, info].
@@ -317,7 +318,7 @@ def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, 
     assert eps_f.numel() == (prob.T - 1) * N
     if f32:
         # float32 arithmetic in the time loops (cbfssm_*_pass_f32), float64 storage; forward evaluation only
-        b32, f32p = pack_b.pack_f32(), pack_f.pack_f32()
+        b32, f32p = pack_b.pack_f32(bf16), pack_f.pack_f32(bf16)
         rc = lib.cbfssm_backward_pass_f32(pb, C.byref(pack_b.layout), C.c_void_p(b32.data_ptr()), _ptr(var_x), _ptr(u),
                                           _ptr(y), _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.ent_part), st)
         _l.check(rc, 'cbfssm_backward_pass_f32')
@@ -362,8 +363,9 @@ class HipElbo:
         cbfssm.py:12, with the Cholesky kept in float64, gp_tf.py:57-65); storage and the ELBO reductions stay float64."""
         self.config = config
         self.device = torch.device(device)
-        assert dtype in ('float64', 'float32')
-        self.f32 = dtype == 'float32'
+        assert dtype in ('float64', 'float32', 'bfloat16')
+        self.f32 = dtype in ('float32', 'bfloat16')
+        self.bf16 = dtype == 'bfloat16'       # bf16 OPERANDS of the K^-1 K contraction inside the float32 passes
         self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
         self.M, self.S = config['ind_pnt_num'], config['samples']
         D = self.dim_x + self.dim_u
@@ -400,7 +402,7 @@ class HipElbo:
         ws = self._ws[key]
         hid_b, eps_b, eps_f = (_f64(noise[k], self.device) for k in ('hid_b', 'eps_b', 'eps_f'))
         elbo_forward(prob, self.pack_f, self.pack_b, self.var_x, self.var_y, u, y, hid_b, eps_b, eps_f,
-                     self.config['loss_factors'], ws, f32=self.f32)
+                     self.config['loss_factors'], ws, f32=self.f32, bf16=self.bf16)
         return ws
 
 

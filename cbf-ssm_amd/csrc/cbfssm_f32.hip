@@ -25,6 +25,18 @@ namespace f32 {
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define CBF_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// float -> the nearest bfloat16 value (round to nearest even on the dropped 16 mantissa bits), kept in a float: the
+// bf16-operand mode of the sweep rounds the two operands of the K^-1 K contraction this way and multiplies them on the
+// float32 MFMA -- products of bf16 values are exact in float32, so this is the arithmetic of a bf16-operand /
+// float32-accumulate MFMA up to the order of the accumulation (it measures the precision, it is not a throughput path).
+__host__ __device__ __forceinline__ float round_bf16(float x)
+{
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    v.u = (v.u + 0x7FFFu + ((v.u >> 16) & 1u)) & 0xFFFF0000u;
+    return v.f;
+}
+
 struct Pack32 {
     const float* Bp;     // [NBLK][KS][64]  K^-1, A-operand image, permuted k order
     const float* Zp;     // [NBLK][DK][64]  Z / lengthscale, A-operand image (natural k order: the inputs' dimensions)
@@ -32,7 +44,7 @@ struct Pack32 {
     const float* mu;     // [NBLK][4][64]   zeta_mean, A-operand image, permuted k order
     const float* s2;     // [NBLK][4][64]   zeta_var
     const float* invl;   // [Dp]
-    const float* scal;   // [0] = sigma^2
+    const float* scal;   // [0] = sigma^2, [1] = 1 when the contraction operands are rounded to bf16
 };
 
 struct Off32 {
@@ -56,7 +68,8 @@ static Off32 pack32_offsets(const cbfssm_pack_layout* L)
 }
 
 __global__ void pack32_kernel(const double* pack, int64_t oBp, int64_t oZp, int64_t ocz, int64_t omu, int64_t os2,
-                              int64_t oinvl, int64_t oscal, float* out, Off32 o, int NBLK, int KS, int DK, int Mp, int Dp)
+                              int64_t oinvl, int64_t oscal, float* out, Off32 o, int NBLK, int KS, int DK, int Mp, int Dp,
+                              int bf16)
 {
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, nt = int64_t(gridDim.x) * blockDim.x;
     // K^-1: target (rb, s, g, nl) holds Kinv[16 rb + nl][16 (s >> 2) + 4 g + (s & 3)]; the f64 image holds
@@ -65,7 +78,8 @@ __global__ void pack32_kernel(const double* pack, int64_t oBp, int64_t oZp, int6
         const int l = int(i & 63), s = int((i >> 6) % KS), rb = int((i >> 6) / KS);
         const int g = l >> 4, nl = l & 15;
         const int sp = 4 * (s >> 2) + g, gp = s & 3;
-        out[o.Bp + i] = float(pack[oBp + (int64_t(rb) * KS + sp) * 64 + gp * 16 + nl]);
+        const float kv = float(pack[oBp + (int64_t(rb) * KS + sp) * 64 + gp * 16 + nl]);
+        out[o.Bp + i] = bf16 ? round_bf16(kv) : kv;
     }
     for (int64_t i = tid; i < int64_t(NBLK) * DK * 64; i += nt) out[o.Zp + i] = float(pack[oZp + i]);
     for (int64_t i = tid; i < Mp; i += nt) out[o.cz + i] = float(pack[ocz + i]);
@@ -78,7 +92,10 @@ __global__ void pack32_kernel(const double* pack, int64_t oBp, int64_t oZp, int6
         out[o.s2 + i] = float(pack[os2 + src]);
     }
     for (int64_t i = tid; i < Dp; i += nt) out[o.invl + i] = float(pack[oinvl + i]);
-    if (tid == 0) out[o.scal] = float(pack[oscal + CBFSSM_SCAL_SIGMA2]);
+    if (tid == 0) {
+        out[o.scal] = float(pack[oscal + CBFSSM_SCAL_SIGMA2]);
+        out[o.scal + 1] = bf16 ? 1.0f : 0.0f;
+    }
 }
 
 struct Args32 {
@@ -132,10 +149,12 @@ struct Tile32 {
     const float* mu;
     const float* s2;
     float sigma2;
+    bool bf16;
 
     __device__ __forceinline__ void load(const Pack32& pk, int w, int l)
     {
         Bp = pk.Bp; mu = pk.mu; s2 = pk.s2; sigma2 = pk.scal[0];
+        bf16 = pk.scal[1] != 0.0f;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int rb = w * RB + i;
@@ -172,6 +191,7 @@ struct Tile32 {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     kreg[i][r] = expf(e[r]);
+                    if (bf16) kreg[i][r] = round_bf16(kreg[i][r]);  // (the kernel tile is the contraction's other operand)
                     Kt[(4 * rb + r) * 64 + l] = kreg[i][r];         // B operand of the (permuted) k-step 4 rb + r
                 }
             } else {
@@ -576,14 +596,24 @@ int64_t cbfssm_pack_f32_elems(const cbfssm_pack_layout* L)
     return pack32_offsets(L).total;
 }
 
-int cbfssm_gp_pack_f32(const cbfssm_pack_layout* L, const double* pack, float* pack32, void* stream)
+static int pack32_launch(const cbfssm_pack_layout* L, const double* pack, float* pack32, int bf16, void* stream)
 {
     if (!L || !pack || !pack32) return fail(-1, "null pointer");
     const Off32 o = pack32_offsets(L);
     hipLaunchKernelGGL(pack32_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, pack, L->Bp, L->Zp, L->cz, L->muA, L->s2A,
-                       L->invl, L->scal, pack32, o, L->NBLK, L->KS, L->DK, L->Mp, L->Dp);
+                       L->invl, L->scal, pack32, o, L->NBLK, L->KS, L->DK, L->Mp, L->Dp, bf16);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-int(e) - 1000, "gp_pack_f32: %s", hipGetErrorString(e));
+}
+
+int cbfssm_gp_pack_f32(const cbfssm_pack_layout* L, const double* pack, float* pack32, void* stream)
+{
+    return pack32_launch(L, pack, pack32, 0, stream);
+}
+
+int cbfssm_gp_pack_bf16(const cbfssm_pack_layout* L, const double* pack, float* pack32, void* stream)
+{
+    return pack32_launch(L, pack, pack32, 1, stream);
 }
 
 int cbfssm_gp_predict_f32(const cbfssm_pack_layout* L, const float* pack32, const double* X, int64_t npts, double* fmean,

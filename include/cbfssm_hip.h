@@ -314,10 +314,15 @@ int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* st
  *   cbfssm_backward_pass_f32 / cbfssm_forward_pass_f32   CBFSSM._backward / _forward (cbfssm.py:84-237); the partial-sum
  *                           buffers have cbfssm_backward_pass_partials / cbfssm_forward_pass_partials entries; feed
  *                           cbfssm_loglik_moments_f64 and cbfssm_elbo_combine_f64 as usual.
+ *   cbfssm_gp_pack_bf16     the same pack with the K^-1 operand rounded to bfloat16; the _f32 passes given such a pack
+ *                           also round the kernel tile to bfloat16, i.e. they evaluate the K^-1 K contraction with
+ *                           bf16 operands and float32 accumulation (on the float32 MFMA: bf16 x bf16 products are exact in
+ *                           float32).  A precision probe for the fp32-vs-bf16 tolerance sweep, not a throughput path.
  * Forward evaluation only: there is no float32 adjoint (training runs in float64).
  */
 int64_t cbfssm_pack_f32_elems(const cbfssm_pack_layout* layout);
 int cbfssm_gp_pack_f32(const cbfssm_pack_layout* layout, const double* pack, float* pack32, void* stream);
+int cbfssm_gp_pack_bf16(const cbfssm_pack_layout* layout, const double* pack, float* pack32, void* stream);
 int cbfssm_gp_predict_f32(const cbfssm_pack_layout* layout, const float* pack32, const double* X, int64_t npts,
                           double* fmean, double* fvar, void* stream);
 int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const float* pack32_b,

@@ -97,8 +97,8 @@ def test_f32_model_surface(tmp_path):
 
 def test_precision_sweep_c5_shape_on_the_gpu():
     """BASELINE.json configs[4]: the ELBO / predictive-moment error of float32 arithmetic against float64 on the
-    RoboMove-shaped problem (M = 300, T = 1000, S = 50, recog_len = 50; B = 8 here), at the run-script initial values and
-    at trained-like parameters.  The numbers go to gpurun_out/precision_sweep_gpu.json (quoted in DESIGN.md)."""
+    RoboMove-shaped problem (M = 300, T = 1000, S = 50, recog_len = 50; B = 8 here) -- and of bf16 operands in the K^-1 K
+    contraction with float32 accumulation -- at the run-script initial values and at trained-like parameters.  The numbers go to gpurun_out/precision_sweep_gpu.json (quoted in DESIGN.md)."""
     w = dataclasses.replace(syn.WORKLOADS['C5'], B=8)
     cfg = w.model_config()
     u, y = syn.make_inputs(w, seed=0)
@@ -107,22 +107,27 @@ def test_precision_sweep_c5_shape_on_the_gpu():
     for tag, p in (('initial', syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)),
                    ('trained_like_ls_x2', syn.trained_like_params(w, ls_mult=2.0, zeta_mean=0.05)),
                    ('trained_like_ls_x3', syn.trained_like_params(w, ls_mult=3.0, zeta_mean=0.05))):
-        e64, e32 = ops.HipElbo(cfg, DEV), ops.HipElbo(cfg, DEV, dtype='float32')
+        e64 = ops.HipElbo(cfg, DEV)
         e64.prepare(p)
-        e32.prepare(p)
         o64 = e64.run(u, y, noise, condition=True)
-        o32 = e32.run(u, y, noise, condition=True)
-        a, b = o64.out.cpu().numpy(), o32.out.cpu().numpy()
+        a = o64.out.cpu().numpy()
         pm64, pv64 = o64.pred_mean.cpu().numpy(), o64.pred_var.cpu().numpy()
-        rep = {'cond_f': float(e64.pack_f.scal[4]), 'cond_b': float(e64.pack_b.scal[4]),
-               'loss_rel': float(abs(b[6] - a[6]) / abs(a[6])),
-               'pred_mean_relmax': float(np.abs(o32.pred_mean.cpu().numpy() - pm64).max() / np.abs(pm64).max()),
-               'pred_var_rel': float((np.abs(o32.pred_var.cpu().numpy() - pv64) / pv64).max())}
+        rep = {'cond_f': float(e64.pack_f.scal[4]), 'cond_b': float(e64.pack_b.scal[4])}
+        for dt in ('float32', 'bfloat16'):      # bfloat16: bf16 operands of the K^-1 K contraction, float32 accumulation
+            e32 = ops.HipElbo(cfg, DEV, dtype=dt)
+            e32.prepare(p)
+            o32 = e32.run(u, y, noise, condition=True)
+            b = o32.out.cpu().numpy()
+            rep[dt] = {'loss_rel': float(abs(b[6] - a[6]) / abs(a[6])),
+                       'pred_mean_relmax': float(np.abs(o32.pred_mean.cpu().numpy() - pm64).max() / np.abs(pm64).max()),
+                       'pred_var_rel': float((np.abs(o32.pred_var.cpu().numpy() - pv64) / pv64).max())}
+            print('\nC5-shape (B=8) %s vs float64, %s: cond f %.1e b %.1e | loss %.1e pred_mean %.1e pred_var %.1e'
+                  % (dt, tag, rep['cond_f'], rep['cond_b'], rep[dt]['loss_rel'], rep[dt]['pred_mean_relmax'],
+                     rep[dt]['pred_var_rel']))
+            assert np.isfinite(b[6])
         report[tag] = rep
-        print('\nC5-shape (B=8) float32 vs float64, %s: cond f %.1e b %.1e | loss %.1e pred_mean %.1e pred_var %.1e'
-              % (tag, rep['cond_f'], rep['cond_b'], rep['loss_rel'], rep['pred_mean_relmax'], rep['pred_var_rel']))
-        assert np.isfinite(b[6])
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     os.makedirs(out, exist_ok=True)
     json.dump(report, open(os.path.join(out, 'precision_sweep_gpu.json'), 'w'), indent=1)
-    assert report['initial']['loss_rel'] <= 1e-4
+    assert report['initial']['float32']['loss_rel'] <= 1e-4
+    assert report['initial']['bfloat16']['loss_rel'] <= 1e-2
