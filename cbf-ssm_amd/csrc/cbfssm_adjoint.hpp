@@ -119,6 +119,14 @@ struct RevLds {
 //   no longer fit into phase F next to wave 3's own); with the operand loads of phases E and F issued early (below):
 //   2 blocks 4.68 / 5.54, 3 blocks 4.30 / 5.40, 4 blocks 4.66 / -.
 constexpr int REV_XCB = 3;
+// ... and it STARTS EARLY.  Its operands of row block rb exist as soon as that row block's wave has written its A2bar rows,
+// a quarter into phase E -- not only after the barrier that ends E.  Measured per wave (profiles/r02/
+// adjoint_phase_shares_per_wave.log): with the whole of its 84 MFMAs between the barriers of phase F, wave 3's SIMD carries
+// 41 + 84 MFMAs there against 82 on the others (phase F 41 % of a step on wave 3, 33-35 % elsewhere, everybody waiting
+// for it) and idles half of phase E (wave 3 waits 9-11 % there).  So the row-block waves raise an LDS flag per row block
+// (flag_release / flag_wait, cbfssm_kernels.hpp) and the extra wave takes the first REV_XEARLY row blocks before that
+// barrier, the rest after it.
+constexpr int REV_XEARLY = 3;
 constexpr bool rev_extra_wave(int nblk, bool stash) { return nblk == 7 && !stash; }
 
 // KD: k-steps of the products whose k index is the GP output dimension (mu Fm, s2 Fv): 4 in general, 2 when the launcher
@@ -151,6 +159,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     double* Fv = Fm + 16 * PD;                          // [16][17]
     double* part = PALIAS ? Kt : (Fv + 16 * PD);        // [W][max(2,JB)][4][64]
     double* red = PALIAS ? (Fv + 16 * PD) : (part + W * PSL);   // 64
+    int* xflag = reinterpret_cast<int*>(red);           // extra wave: "A2bar rows of row block rb are written" flags
+                                                        // (red itself is only used by the block sums after the time loop)
     double* Bl = red + 64;                              // BLDS: [NBLK][KSr][64]
     constexpr bool ZLDS = RL::ZLDS && !BLDS, ZTLDS = RL::ZTLDS && !BLDS, MULDS = RL::MULDS && !BLDS;
     double* ZTl = red + 64;                             // ZTLDS: [NBLK][JB][4][64]
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     for (int i = tid; i < 2 * 4 * DK * PD; i += NT) xq0[i] = 0.0;
     double* xq = xq0;
     for (int i = tid; i < 16 * PD; i += NT) { Fm[i] = 0.0; Fv[i] = 0.0; }
+    if (tid < 64) { xflag[tid] = 0; xflag[tid + 64] = 0; }
     if (BLDS) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -450,22 +461,39 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 for (int cq = 0; cq < XCB; ++cq) xacc[rb][cq] = d4{0, 0, 0, 0};
             __syncthreads();                                         // (the barrier in front of the step loop)
             for (int step = 0; step < nsteps; ++step) {
-                __syncthreads();                                     // 1: kernel tile complete
-                __syncthreads();                                     // 4: A2bar tile complete, K tile still intact
+                __syncthreads();                                     // 1: kernel tile complete (and intact until barrier 6)
                 double kT[XCB][4];
 #pragma unroll
                 for (int cq = 0; cq < XCB; ++cq)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) kT[cq][s] = Kt[(16 * (NCB + cq) + nl) * PD + 4 * s + g];
+                // the first row blocks while the row-block waves are still in phase E (their A2bar rows are flagged) ...
 #pragma unroll
                 for (int rb = 0; rb < NBLK; ++rb) {
-                    double abT[4];
+                    if (rb < REV_XEARLY) {
+                        flag_wait(xflag, rb, step + 1);
+                        double abT[4];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) abT[s] = A2t[(16 * rb + nl) * PD + 4 * s + g];
+                        for (int s = 0; s < 4; ++s) abT[s] = A2t[(16 * rb + nl) * PD + 4 * s + g];
 #pragma unroll
-                    for (int cq = 0; cq < XCB; ++cq)
+                        for (int cq = 0; cq < XCB; ++cq)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) xacc[rb][cq] = CBF_MFMA(abT[s], kT[cq][s], xacc[rb][cq]);
+                            for (int s = 0; s < 4; ++s) xacc[rb][cq] = CBF_MFMA(abT[s], kT[cq][s], xacc[rb][cq]);
+                    }
+                }
+                __syncthreads();                                     // 4: every A2bar row is written
+                // ... the rest inside phase F
+#pragma unroll
+                for (int rb = 0; rb < NBLK; ++rb) {
+                    if (rb >= REV_XEARLY) {
+                        double abT[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) abT[s] = A2t[(16 * rb + nl) * PD + 4 * s + g];
+#pragma unroll
+                        for (int cq = 0; cq < XCB; ++cq)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) xacc[rb][cq] = CBF_MFMA(abT[s], kT[cq][s], xacc[rb][cq]);
+                    }
                 }
                 __syncthreads();                                     // 5
                 __syncthreads();                                     // 6
@@ -676,6 +704,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) own[(g + 4 * r) * PD + nl] = a2bar[i][r];   // stays: A2bar tile of phase F
+                if constexpr (XW) flag_release(xflag + rbs[i], step + 1);               // the extra wave may take this block
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     gMu[i] = CBF_MFMA(a2T[s], fmT[s], gMu[i]);                  // mubar[m][d] += A2[m][n] Fm[d][n]
@@ -1087,7 +1116,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         slab[SL::small + 97] = s2;
     }
 #ifdef CBF_REV_STAMPS
-    if (l == 0 && (w == 0 || w == W - 1)) {
+#ifndef CBF_STAMP_WAVE
+#define CBF_STAMP_WAVE (W - 1)          // the second wave whose phase shares are recorded (-DCBF_STAMP_WAVE=k picks another)
+#endif
+    if (l == 0 && (w == 0 || w == CBF_STAMP_WAVE)) {
         const int o = (w == 0) ? 100 : 114;
         for (int i = 0; i < 7; ++i) {
             slab[SL::small + o + i] = double(st_c[i]);
