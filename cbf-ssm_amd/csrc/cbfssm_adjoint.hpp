@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 #pragma unroll
     for (int k2 = 0; k2 < AUXR; ++k2) {
         const int i = (NT - 1 - tid) + k2 * NT, ja = i >> 4, n = i & 15;   // from the last wave down: waves 0-3 carry D/G
-        auxp[k2] = nullptr; auxs[k2] = 0; auxl[k2] = 0.0;
+        auxp[k2] = a.pk.invl; auxs[k2] = 0; auxl[k2] = 0.0;            // (no row: a valid dummy address, factor 0)
         if (i >= 0 && i < 16 * naux) {
             const int b = min(c0 + n, N - 1) / S;
             if (ja < a.dim_u) { auxp[k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[k2] = a.dim_u; }
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
             }
         }
 #pragma unroll
-        for (int k2 = 0; k2 < AUXR; ++k2) av[k2] = auxp[k2] ? auxp[k2][int64_t(t) * auxs[k2]] * auxl[k2] : 0.0;
+        for (int k2 = 0; k2 < AUXR; ++k2) av[k2] = auxp[k2][int64_t(t) * auxs[k2]];   // raw: scaled in store_inputs (a multiply
+                                                                                        // here is a vmcnt(0) wait at the step top)
     };
     auto store_inputs = [&](double* xb, const double (&hv)[QPW], const double (&av)[AUXR]) {
 #pragma unroll
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = (NT - 1 - tid) + k2 * NT;
-            if (i < 16 * naux) xb[(Do + (i >> 4)) * PD + (i & 15)] = av[k2];
+            if (i < 16 * naux) xb[(Do + (i >> 4)) * PD + (i & 15)] = av[k2] * auxl[k2];
         }
     };
     // phase D of step t: adjoint of the step epilogue from the carried state adjoint -> Fm, Fv tiles, gdir

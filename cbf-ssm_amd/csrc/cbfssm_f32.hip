@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
 #pragma unroll
     for (int k2 = 0; k2 < AUXR; ++k2) {
         const int i = tid + k2 * NT, ja = i >> 4, n = i & 15;
-        auxp[k2] = nullptr; auxs[k2] = 0; auxl[k2] = 0.0f;
+        auxp[k2] = a.eps; auxs[k2] = 0; auxl[k2] = 0.0f;       // (no row: a valid dummy address -- loads only happen when a next step exists --, factor 0)
         if (i < 16 * naux) {
             const int b = min(c0 + n, N - 1) / S;
             if (ja < a.dim_u) { auxp[k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[k2] = a.dim_u; }
@@ -374,9 +374,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
             auxl[k2] = a.pk.invl[Do + ja];
         }
     }
-    auto aux_load = [&](int k2, int t) -> float {
-        return auxp[k2] ? float(auxp[k2][int64_t(t) * auxs[k2]]) * auxl[k2] : 0.0f;
-    };
+    // raw float64 value: converted and scaled at the LDS write (see pass_kernel in cbfssm_kernels.hpp)
+    auto aux_load = [&](int k2, int t) -> double { return auxp[k2][int64_t(t) * auxs[k2]]; };
 
     for (int i = tid; i < DK * 64; i += NT) xq[i] = 0.0f;
     __syncthreads();
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
 #pragma unroll
     for (int k2 = 0; k2 < AUXR; ++k2) {
         const int i = tid + k2 * NT;
-        if (i < 16 * naux) xq[16 * Do + i] = aux_load(k2, t_first);
+        if (i < 16 * naux) xq[16 * Do + i] = float(aux_load(k2, t_first)) * auxl[k2];
     }
 
     for (int step = 0; step < nsteps; ++step) {
@@ -414,7 +413,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
         const bool has_next = (step + 1 < nsteps);
         __syncthreads();                                  // xq complete
 
-        float eps_t, ytil[QPW], hidn = 0.0f, auxr[AUXR];
+        float eps_t, ytil[QPW], hidn = 0.0f;
+        double auxr[AUXR];
         bool resample_n = false;
         if (MODE == MODE_BWD) resample_n = has_next && (tmn + 1 + run * R == P);            // cbfssm.py:124,127
         if (MODE == MODE_FWD) {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
             for (int qi = 0; qi < QPW; ++qi) ytil[qi] = 0.0f;
         }
 #pragma unroll
-        for (int k2 = 0; k2 < AUXR; ++k2) auxr[k2] = has_next ? aux_load(k2, tn) : 0.0f;
+        for (int k2 = 0; k2 < AUXR; ++k2) auxr[k2] = has_next ? aux_load(k2, tn) : 0.0;
 
         tile.gp(xq, Kt, part, w, l);                      // (one workgroup barrier inside)
         __syncthreads();                                  // part complete; xq and Kt free
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
 #pragma unroll
             for (int k2 = 0; k2 < AUXR; ++k2) {
                 const int i = tid + k2 * NT;
-                if (i < 16 * naux) xq[16 * Do + i] = auxr[k2];
+                if (i < 16 * naux) xq[16 * Do + i] = float(auxr[k2]) * auxl[k2];
             }
         }
     }

@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT, ja = i >> 4, n = i & 15;
-            auxp[cb][k2] = nullptr; auxs[cb][k2] = 0; auxl[cb][k2] = 0.0;
+            auxp[cb][k2] = a.pk.invl; auxs[cb][k2] = 0; auxl[cb][k2] = 0.0;   // (no row: a valid dummy address, factor 0)
             if (i < 16 * naux) {
                 const int b = min(c0 + cb * 16 + n, N - 1) / S;
                 if (ja < a.dim_u) { auxp[cb][k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[cb][k2] = a.dim_u; }
@@ -1072,9 +1072,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
                 auxl[cb][k2] = a.pk.invl[Do + ja];
             }
         }
-    auto aux_load = [&](int cb, int k2, int t) -> double {
-        return auxp[cb][k2] ? auxp[cb][k2][int64_t(t) * auxs[cb][k2]] * auxl[cb][k2] : 0.0;
-    };
+    // The raw value: the 1/lengthscale factor is applied where the row is written to LDS.  (A multiply right behind the
+    // load makes the compiler wait for it -- and, vmcnt being in-order, for the noise / observation loads issued before
+    // it -- at the top of every step, on the waves everybody then waits for at the barrier.)
+    auto aux_load = [&](int cb, int k2, int t) -> double { return auxp[cb][k2][int64_t(t) * auxs[cb][k2]]; };
 
     // ---- initial state and first input
     // xq rows [0,Do) carry the chain state, rows [Do,D) the auxiliary inputs, rows [D,4*DK) stay zero
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT;
-            if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = aux_load(cb, k2, t_first);
+            if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = aux_load(cb, k2, t_first) * auxl[cb][k2];
         }
 
     CBF_STAMP_DECL;
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 #pragma unroll
                 for (int k2 = 0; k2 < AUXR; ++k2) {
                     const int i = tid + k2 * NT;
-                    if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = auxr[cb][k2];
+                    if (i < 16 * naux) xq[cb * XS + 16 * Do + i] = auxr[cb][k2] * auxl[cb][k2];
                 }
         }
     }
@@ -1353,7 +1354,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT, ja = i >> 4, n = i & 15;
-            auxp[cb][k2] = nullptr; auxs[cb][k2] = 0; auxl[cb][k2] = 0.0;
+            auxp[cb][k2] = a.pk.invl; auxs[cb][k2] = 0; auxl[cb][k2] = 0.0;   // (no row: a valid dummy address, factor 0)
             if (i < 16 * naux) {
                 const int b = min(c0 + cb * 16 + n, N - 1) / S;
                 if (ja < a.dim_u) { auxp[cb][k2] = a.u + int64_t(b) * T * a.dim_u + ja; auxs[cb][k2] = a.dim_u; }
@@ -1361,9 +1362,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
                 auxl[cb][k2] = a.pk.invl[Do + ja];
             }
         }
-    auto aux_load = [&](int cb, int k2, int t) -> double {
-        return auxp[cb][k2] ? auxp[cb][k2][int64_t(t) * auxs[cb][k2]] * auxl[cb][k2] : 0.0;
-    };
+    // (the raw value; the 1/lengthscale factor is applied at the LDS write, see pass_kernel)
+    auto aux_load = [&](int cb, int k2, int t) -> double { return auxp[cb][k2][int64_t(t) * auxs[cb][k2]]; };
 
     // ---- initial state and first input of both groups
     for (int i = tid; i < 2 * XS; i += NT) xq[i] = 0.0;
@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) {
             const int i = tid + k2 * NT;
-            if (i < 16 * naux) xq[c * XS + 16 * Do + i] = aux_load(c, k2, t_first);
+            if (i < 16 * naux) xq[c * XS + 16 * Do + i] = aux_load(c, k2, t_first) * auxl[c][k2];
         }
     }
     __syncthreads();
@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
 #pragma unroll
             for (int k2 = 0; k2 < AUXR; ++k2) {
                 const int i = tid + k2 * NT;
-                if (i < 16 * naux) xq[c * XS + 16 * Do + i] = auxn[k2];
+                if (i < 16 * naux) xq[c * XS + 16 * Do + i] = auxn[k2] * auxl[c][k2];
             }
         }
     };
