@@ -554,11 +554,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 
         // mean / variance B operands of phase E: issued here (eight-wave tiles: the registers are there), under phase B
         // (measured: forward-pass adjoint 4.47 -> 4.32 ms; the backward runs do not gain: 5.42 -> 5.45)
-        constexpr bool MUPRE = XW && RB == 1 && MODE == MODE_FWD;
+        constexpr bool MUPRE = XW && RB == 1;
         double mBv[MUPRE ? 4 : 1], sBv[MUPRE ? 4 : 1];
         if constexpr (MUPRE) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < KD; ++s) {
                 mBv[s] = a.rk.muB[rbs[0] * 256 + s * 64 + l];
                 sBv[s] = a.rk.s2B[rbs[0] * 256 + s * 64 + l];
             }
@@ -594,11 +594,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 #pragma unroll
                     for (int s = 0; s < DK; ++s) e = CBF_MFMA(tile.Zreg[i][s], bx[s], e);
                 }
+                kreg[i] = tile_exp4(e);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    kreg[i][r] = tile_exp(e[r]);
-                    Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
-                }
+                for (int r = 0; r < 4; ++r) Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
             }
         }
         CBF_STAMP_BARRIER(1);

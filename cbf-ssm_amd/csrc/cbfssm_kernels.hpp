@@ -70,6 +70,43 @@ __device__ __forceinline__ double tile_exp(double x)
     return __builtin_amdgcn_ldexp(p, int(k));
 }
 
+// The four exponentials of a lane's kernel-tile rows, stage by stage: each stage is four independent instructions, so
+// the four dependent chains of tile_exp interleave in program order (left to the scheduler, the four inlined copies
+// are issued one after the other and every multiply-add waits for its predecessor's result).  Same operations per
+// element as tile_exp: bitwise the same result.  (The clamp as one v_max_f64: fmax() also emits a canonicalising
+// v_max_f64 x, x in front of it -- the argument is an MFMA result or the -1e30 row constant, never a signalling NaN.)
+__device__ __forceinline__ d4 tile_exp4(d4 x)
+{
+    double k[4], r[4], p[4];
+    const double lo = -746.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double y;
+        asm("v_max_f64 %0, %1, %2" : "=v"(y) : "v"(x[i]), "v"(lo));
+        x[i] = y;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[i] = __builtin_rint(x[i] * 1.4426950408889634074);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fma(-k[i], 6.93147180369123816490e-01, x[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fma(-k[i], 1.90821492927058770002e-10, r[i]);
+    constexpr double c[13] = {2.08767569878680989792e-09, 2.50521083854417187751e-08, 2.75573192239858906526e-07,
+                              2.75573192239858906526e-06, 2.48015873015873015873e-05, 1.98412698412698412698e-04,
+                              1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
+                              1.66666666666666666667e-01, 0.5, 1.0, 1.0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = 1.60590438368216145994e-10;
+#pragma unroll
+    for (int j = 0; j < 13; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = fma(p[i], r[i], c[j]);
+    d4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_ldexp(p[i], int(k[i]));
+    return o;
+}
+
 enum { MODE_FWD = 0, MODE_BWD = 1 };
 
 // Diagnostic build only (-DCBF_REV_STAMPS): per-phase cycle shares of the adjoint step, compute vs barrier wait, summed
@@ -666,9 +703,10 @@ struct Tile {
                     for (int r = 0; r < 4; ++r) e[r] = czr[i][r] - 0.5 * xx;
 #pragma unroll
                     for (int s = 0; s < DK; ++s) e = CBF_MFMA(Zreg[i][s], bx[s], e);
+                    const d4 ev = tile_exp4(e);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        kreg[c][i][r] = tile_exp(e[r]);
+                        kreg[c][i][r] = ev[r];
                         Kt[c * KTS + 256 * rb + 64 * r + l] = kreg[c][i][r];
                     }
                 } else {
@@ -785,9 +823,10 @@ struct Tile {
                 for (int r = 0; r < 4; ++r) e[r] = czr[i][r] - 0.5 * xx;
 #pragma unroll
                 for (int s = 0; s < DK; ++s) e = CBF_MFMA(Zreg[i][s], bx[s], e);
+                const d4 ev = tile_exp4(e);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    kreg[i][r] = tile_exp(e[r]);
+                    kreg[i][r] = ev[r];
                     Kt[256 * rb + 64 * r + l] = kreg[i][r];
                 }
             } else {
