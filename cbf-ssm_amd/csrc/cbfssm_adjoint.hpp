@@ -68,6 +68,7 @@ struct RevArgs {
     const double* a2s;     // optional: A2 = K^-1 k tiles of every step as saved by the forward evaluation
                            // (PassArgs::a2s layout); NULL -> phase C recomputes them
     const double* fmv;     // (fmean, fvar) of every step as saved by the forward evaluation (PassArgs::fmv layout)
+    int ksave;             // 1: every saved record is [A2 tile][kernel tile] (PassArgs::ksave)
 };
 
 // slab layout (doubles), all in MFMA C-layout [r][lane] blocks of 256
@@ -131,9 +132,13 @@ constexpr bool rev_extra_wave(int nblk, bool stash) { return nblk == 7 && !stash
 
 // KD: k-steps of the products whose k index is the GP output dimension (mu Fm, s2 Fv): 4 in general, 2 when the launcher
 // knows Do <= 8 (the backward runs of the Sarcos class: dim_x - dim_y = 7) -- the other two would multiply zeros.
-template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE, int KD = 4>
+// KSV: the forward evaluation kept the kernel tile of every step next to its A2 tile (RevArgs::ksave, non-stash tiles):
+// phase B is a copy -- registers that were loaded a step ahead go to the LDS tile -- instead of 6 MFMAs and four
+// exponentials per lane, and the Z~ rows / row constants of the wave are not held at all.
+template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE, int KD = 4, bool KSV = false>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, STASH) ? 1 : 0))) void rev_kernel(RevArgs a)
 {
+    static_assert(!(KSV && STASH), "kernel tiles are kept for the register-resident tile heights only");
     constexpr bool BREG = false;
     typedef Tile<NBLK, RB, DK, BREG> TT;
     constexpr int W = TT::W, NT = TT::NT, MP = TT::MP, KS = TT::KS;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     // ---- loop-invariant operands (Z~ rows and cz of the owned row blocks stay in VGPRs; the small operand images
     // muA/s2A/muB/s2B/ZT are re-read from L1/L2 where they are used: the VGPRs hold the adjoint accumulators)
     TT tile;
-    tile.template load_operands<false>(a.pk, w, l);
+    if constexpr (!KSV) tile.template load_operands<false>(a.pk, w, l);
     bool ok[RB];
     int rbs[RB];
 #pragma unroll
@@ -519,6 +524,46 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         epilogue_load(t_of(0), e0, y0, m0, v0);
         epilogue_adjoint(t_of(0), tmod, e0, y0, m0, v0);
     }
+    // KSV: the saved [A2 | K] rows of this wave for the NEXT step, issued behind barrier 5 of the current one
+    const int64_t G16 = (N + 15) >> 4;
+    const int TS = saved_tile_stride(NBLK, a.ksave);
+    d4 a2n[KSV ? RB : 1], kn[KSV ? RB : 1];
+    auto load_saved = [&](int t) {
+        if constexpr (KSV) {
+            const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+            const double* ap = a.a2s + (slot * G16 + (c0 >> 4)) * TS + l;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a2n[i][r] = ap[rbs[i] * 256 + r * 64];
+                    kn[i][r] = ap[NBLK * 256 + rbs[i] * 256 + r * 64];
+                }
+            }
+        }
+    };
+    if (nsteps > 0) load_saved(t_of(0));
+    // mean / variance B operands of phase E (eight-wave tiles).  Without the kernel-tile build the step has no phase whose
+    // arithmetic would hide their latency, and the Z~ rows it no longer holds leave the registers: KSV keeps them for the pass.
+    constexpr bool MUPRE = XW && RB == 1;
+    double mBv[MUPRE ? 4 : 1], sBv[MUPRE ? 4 : 1];
+    auto load_mu = [&]() {
+        if constexpr (MUPRE) {
+#pragma unroll
+            for (int s = 0; s < KD; ++s) {
+                mBv[s] = a.rk.muB[rbs[0] * 256 + s * 64 + l];
+                sBv[s] = a.rk.s2B[rbs[0] * 256 + s * 64 + l];
+            }
+        }
+    };
+    // (two k-steps = 8 registers: the backward runs of the Sarcos class; four would spill in the forward-pass adjoint)
+    constexpr bool MURES = KSV && MUPRE && KD == 2;
+    if constexpr (MURES) {
+        load_mu();
+        // landed before the loop: otherwise the compiler has to assume them in flight at the loop header and its first
+        // wait inside the loop also waits, in every iteration, for whatever the step has issued by then
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    }
     __syncthreads();
     CBF_STAMP_START();
 #ifdef CBF_REV_STAMPS
@@ -534,14 +579,28 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         const int tmn = (tmod + 1 == P) ? 0 : tmod + 1;             // (t + 1) mod 2R: the backward-run adjoint walks t upwards
         if (MODE == MODE_BWD) resample_t = (tmod + 1 + run * R == P);                         // cbfssm.py:124,127
 
-        // next step's inputs: issued now, written to LDS after the kernel tile
+        // ---- B with kept kernel tiles (KSV): the rows loaded a step ahead go to the LDS tile -- FIRST thing in the step:
+        // vmcnt retires in order, so anything issued before this wait (the next step's inputs below) would be waited for too
+        d4 kreg[RB];
+        if constexpr (KSV) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                kreg[i] = kn[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
+            }
+        }
+        // next step's inputs: issued now, written to LDS at the end of phase E
         double hnext[QPW], auxn[AUXR];
         if (has_next) load_inputs(tn, tmn, hnext, auxn);
         // A2 rows of this wave, if the forward evaluation kept them (consumed after the second barrier)
         d4 a2[RB];
-        if (a.a2s) {
+        if constexpr (KSV) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) a2[i] = a2n[i];
+        } else if (a.a2s) {
             const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
-            const double* ap = a.a2s + (slot * ((N + 15) >> 4) + (c0 >> 4)) * (NBLK * 256) + l;
+            const double* ap = a.a2s + (slot * G16 + (c0 >> 4)) * TS + l;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 a2[i] = d4{0, 0, 0, 0};
@@ -552,19 +611,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
             }
         }
 
-        // mean / variance B operands of phase E: issued here (eight-wave tiles: the registers are there), under phase B
-        // (measured: forward-pass adjoint 4.47 -> 4.32 ms; the backward runs do not gain: 5.42 -> 5.45)
-        constexpr bool MUPRE = XW && RB == 1;
-        double mBv[MUPRE ? 4 : 1], sBv[MUPRE ? 4 : 1];
-        if constexpr (MUPRE) {
-#pragma unroll
-            for (int s = 0; s < KD; ++s) {
-                mBv[s] = a.rk.muB[rbs[0] * 256 + s * 64 + l];
-                sBv[s] = a.rk.s2B[rbs[0] * 256 + s * 64 + l];
-            }
-        }
+        // mean / variance B operands of phase E: issued here, under phase B
+        // (measured: forward-pass adjoint 4.47 -> 4.32 ms)
+        if constexpr (!MURES) load_mu();
 
         // ---- B: kernel tile (rows of this wave)
+        if constexpr (!KSV) {
         double bx[DK], xx = 0.0;
 #pragma unroll
         for (int s = 0; s < DK; ++s) {
@@ -573,7 +625,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         }
         xx += __shfl_xor(xx, 16);
         xx += __shfl_xor(xx, 32);
-        d4 kreg[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             kreg[i] = d4{0, 0, 0, 0};
@@ -598,6 +649,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
             }
+        }
         }
         CBF_STAMP_BARRIER(1);
 
@@ -878,7 +930,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 // 32 registers across phases E and F: K from this wave's own rows of the LDS tile, A2 from L2
                 const bool a2_saved = (a.a2s != nullptr);
                 const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
-                const double* ap = a2_saved ? a.a2s + (slot * ((N + 15) >> 4) + (c0 >> 4)) * (NBLK * 256) + l : nullptr;
+                const double* ap = a2_saved ? a.a2s + (slot * G16 + (c0 >> 4)) * TS + l : nullptr;
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -959,6 +1011,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
         }
         CBF_STAMP_BARRIER(5);
+        if (has_next) load_saved(tn);      // (KSV) a2 / kreg were last read in phase F
 
         // ---- G: input adjoint, carried to the next reverse step
         double esum = 0.0;   // colsum of Ebar for this lane's chain = row D of the xbar tile

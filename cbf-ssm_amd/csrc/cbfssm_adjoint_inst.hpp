@@ -33,20 +33,41 @@ int launch_rev_k(const RevArgs& a, dim3 grid, hipStream_t st)
     typedef RevGeom<NBLK, DK> G;
     typedef RevCfg<NBLK> C;
     const int blds_doubles = NBLK * a.KSr * 64;
+    const dim3 block(64 * (C::W + (rev_extra_wave(NBLK, C::STASH) ? 1 : 0)));
     if (G::LDS_BASE + blds_doubles <= G::LDS_LIMIT && !getenv("CBFSSM_NO_BLDS")) {
         const size_t lds = size_t(G::LDS_BASE + blds_doubles) * sizeof(double);
+        if constexpr (!C::STASH) {
+            if (a.ksave && a.a2s) {          // the kernel tiles were kept next to the A2 tiles
+                auto k = rev_kernel<NBLK, C::RB, DK, true, C::STASH, MODE, KD, true>;
+                int rc = set_lds(k, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k, grid, block, lds, st, a);
+                hipError_t e = hipGetLastError();
+                return e == hipSuccess ? 0 : -int(e) - 1000;
+            }
+        }
         auto k = rev_kernel<NBLK, C::RB, DK, true, C::STASH, MODE, KD>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(64 * (C::W + (rev_extra_wave(NBLK, C::STASH) ? 1 : 0))), lds, st, a);
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);
     } else {
         typedef RevLds<NBLK, C::RB, DK, C::STASH> RL;
         static_assert(RL::BASE_PLAIN == G::LDS_BASE, "LDS layout");
         const size_t lds = size_t(RL::BASE + RL::EXTRA) * sizeof(double);
+        if constexpr (!C::STASH) {
+            if (a.ksave && a.a2s) {
+                auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE, KD, true>;
+                int rc = set_lds(k, lds);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k, grid, block, lds, st, a);
+                hipError_t e = hipGetLastError();
+                return e == hipSuccess ? 0 : -int(e) - 1000;
+            }
+        }
         auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE, KD>;
         int rc = set_lds(k, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k, grid, dim3(64 * (C::W + (rev_extra_wave(NBLK, C::STASH) ? 1 : 0))), lds, st, a);
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;

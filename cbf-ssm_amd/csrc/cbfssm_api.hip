@@ -932,6 +932,8 @@ int64_t cbfssm_backward_pass_partials(const cbfssm_problem* p)
     return groups * (n0 + n1);
 }
 
+static int save_k(const cbfssm_pack_layout* L);
+
 int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* L, const double* pack_b,
                              const double* var_x, const double* u, const double* y, const double* hid_b,
                              const double* eps_b, double* y2, double* h_all, double* fmv_b, double* a2s_b,
@@ -952,6 +954,7 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.dbg = g_dbg;
     a.fmv = fmv_b;
     a.a2s = a2s_b;
+    a.ksave = save_k(L);
     int n0, n1;
     bwd_segments(p, &n0, &n1);
     a.nseg0 = n0;
@@ -967,12 +970,17 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
     return 0;
 }
 
+// Tile heights whose adjoint holds its accumulators in registers (M <= 112) also keep the kernel tile K = k(Z, x_t) of
+// every step next to its A2 tile: the adjoint then reads it instead of rebuilding it (6 MFMAs and four exponentials per
+// lane and step, a whole phase of its step), for as many bytes again.  CBFSSM_NO_SAVE_K=1 switches it off (A/B runs).
+static int save_k(const cbfssm_pack_layout* L) { return (L->NBLK <= 7 && !getenv("CBFSSM_NO_SAVE_K")) ? 1 : 0; }
+
 int64_t cbfssm_saved_a2_elems(const cbfssm_problem* p, const cbfssm_pack_layout* L, int backward)
 {
     if (!p || !L) return -1;
     const int64_t g16 = (int64_t(p->B) * p->S + 15) / 16;
     const int64_t slots = backward ? 2 * int64_t(p->T) : (p->T > 1 ? p->T - 1 : 0);
-    return slots * g16 * L->NBLK * 256;
+    return slots * g16 * saved_tile_stride(L->NBLK, save_k(L));
 }
 
 int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p)
@@ -1003,6 +1011,7 @@ static int forward_pass_impl(const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.half = p->half; a.x0 = x0;
     a.fmv = fmv_f;
     a.a2s = a2s_f;
+    a.ksave = save_k(L);
     a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
     const int nc = a.tri ? 1 : pass_nc(p, MODE_FWD);
     int g0, ng, gt;
@@ -1148,6 +1157,7 @@ static int forward_pass_bwd_impl(const cbfssm_problem* p, const cbfssm_pack_layo
     a.half = p->half; a.gx0 = gx0;
     a.fmv = fmv_f;
     a.a2s = a2s_f;
+    a.ksave = a2s_f ? save_k(L) : 0;
     const int64_t groups = (a.N + 15) / 16;
     const int steps = t_hi >= t_lo ? t_hi - t_lo + 1 : 0;
     rc = set_stash(a, L, stash_a, stash_k, stash_ld, groups, steps);
@@ -1213,6 +1223,7 @@ int cbfssm_backward_pass_bwd_ex_f64(const cbfssm_problem* p, const cbfssm_pack_l
     a.gy2 = const_cast<double*>(gy2); a.gpart = gpart;
     a.fmv = fmv_b;
     a.a2s = a2s_b;
+    a.ksave = a2s_b ? save_k(L) : 0;
     a.seg0 = seg0; a.seg1 = seg1; a.nchunk = nchunk;
     const int64_t groups = (a.N + 15) / 16;
     const int per = (seg1 - seg0 + nchunk - 1) / nchunk;

@@ -352,7 +352,12 @@ struct PassArgs {
     double* fmv;           // optional: per-step (fmean, fvar) after residual / process noise, kept for the adjoint:
                            // fwd [(T-1)][N][dim_x][2], bwd [2][T][N][dim_x-dim_y][2]
     int tri;               // 1: GP conditional in the reference's two-triangular form (gp_tf.py:137-145), 0: K^-1 contraction
+    int ksave;             // 1: the kernel tile K = k(Z, x_t) of every step is kept next to its A2 tile: a saved record is
+                           // [A2: NBLK*256][K: NBLK*256] and the adjoint reads K instead of recomputing it (MFMA + exp)
 };
+
+// doubles per saved record (one step, one 16-chain group) -- the pass kernels (writers) and the adjoint (reader) agree on it
+__host__ __device__ constexpr int saved_tile_stride(int nblk, int ksave) { return nblk * 256 * (ksave ? 2 : 1); }
 
 struct PredictArgs {
     PackPtrs pk;
@@ -423,6 +428,7 @@ struct Tile {
     int lane_;
     double sigma2;
     int KSr;       // k-steps of K^-1 that carry data: ceil(M/4) <= KS
+    int koff;      // > 0: the kernel tile is kept too, koff doubles behind the A2 tile of its record (PassArgs::ksave)
 
     template <bool WITH_EPI = true>
     __device__ __forceinline__ void load_operands(const PackPtrs& pk, int w, int l)
@@ -435,6 +441,7 @@ struct Tile {
         lane_ = l;
         sigma2 = pk.scal[0];
         KSr = pk.KSr;
+        koff = 0;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int rb = rb_of(w, i);
@@ -779,8 +786,13 @@ struct Tile {
                 if (rb < NBLK) {
                     const d4 a2 = acc[c][i][0] + acc[c][i][1];
                     if (a2o && c < ncol_ok) {
+                        double* rec = a2o + c * (NBLK * 256 + koff) + rb * 256 + l;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a2o[(c * NBLK + rb) * 256 + r * 64 + l] = a2[r];
+                        for (int r = 0; r < 4; ++r) rec[r * 64] = a2[r];
+                        if (koff) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) rec[koff + r * 64] = kreg[c][i][r];
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -882,6 +894,10 @@ struct Tile {
                 if (a2o) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a2o[rb * 256 + r * 64 + l] = a2[r];
+                    if (koff) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a2o[koff + rb * 256 + r * 64 + l] = kreg[i][r];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1052,6 +1068,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
 
     TT tile;
     tile.load_operands(a.pk, w, l);
+    tile.koff = a.ksave ? NBLK * 256 : 0;
     if constexpr (TT::EPI_LDS && NC == 1) {
         // streamed-K^-1 tiles re-read the mean / variance operand images every step: from LDS (100 KB are free next to
         // the tiles) instead of through an L1 that the K^-1 stream keeps flushing
@@ -1195,11 +1212,24 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         double* a2o = nullptr;                        // this step's A2 tiles, kept for the adjoint
         if (a.a2s) {
             const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
-            a2o = a.a2s + (slot * G16 + int64_t(gx) * NC) * (NBLK * 256);
+            a2o = a.a2s + (slot * G16 + int64_t(gx) * NC) * (NBLK * 256 + tile.koff);
         }
         if constexpr (NC == 1) {
             double kr[RB][4];
             tile.phase1(xq, Kt, kr, w, l);
+            if constexpr (TRI) {
+                // (the dense form's phase 2 writes the kernel tile next to its A2 rows; the two-triangular one does not see it)
+                if (a2o && tile.koff) {
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) {
+                        const int rb = tile.rb_of(w, i);
+                        if (rb < NBLK) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a2o[tile.koff + rb * 256 + r * 64 + l] = kr[i][r];
+                        }
+                    }
+                }
+            }
             CBF_STAMP_BARRIER(1);
             if constexpr (TRI) tile.phase2_tri(Kt, At, flag, step + 1, part, w, l, a2o);
             else tile.phase2(Kt, part, kr, w, l, a2o);
@@ -1356,6 +1386,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
 
     TT tile;
     tile.load_operands(a.pk, w, l);
+    tile.koff = a.ksave ? NBLK * 256 : 0;
 
     // phase-3 tasks: group c, row group q = wq + qi*W (< 4) with wq = w for group A and W-1-w for group B
     double vx[2][QPW], vy[2][QPW], il[2][QPW], hcur[2][QPW], lin[2][QPW];
@@ -1532,7 +1563,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel_skew(
         if (!a.a2s || 2 * gx + c >= G16) return nullptr;
         const int t = t_first + dir * s;
         const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
-        return a.a2s + (slot * G16 + 2 * gx + c) * (NBLK * 256);
+        return a.a2s + (slot * G16 + 2 * gx + c) * (NBLK * 256 + tile.koff);
     };
     tile.phase1(xq, Kt, kregA, w, l);                                   // phase1(A, 0)
     __syncthreads();
