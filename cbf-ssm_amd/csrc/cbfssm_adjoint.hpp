@@ -119,7 +119,10 @@ struct RevLds {
 //   1 block 5.14 / 5.59, 2 blocks 4.89 / 5.60, 3 blocks 4.81 / 5.72, 4 blocks 5.11 / 6.01 (the extra wave's 112 MFMAs
 //   no longer fit into phase F next to wave 3's own); with the operand loads of phases E and F issued early (below):
 //   2 blocks 4.68 / 5.54, 3 blocks 4.30 / 5.40, 4 blocks 4.66 / -.
-constexpr int REV_XCB = 3;
+#ifndef CBF_REV_XCB
+#define CBF_REV_XCB 3
+#endif
+constexpr int REV_XCB = CBF_REV_XCB;
 // ... and it STARTS EARLY.  Its operands of row block rb exist as soon as that row block's wave has written its A2bar rows,
 // a quarter into phase E -- not only after the barrier that ends E.  Measured per wave (profiles/r02/
 // adjoint_phase_shares_per_wave.log): with the whole of its 84 MFMAs between the barriers of phase F, wave 3's SIMD carries
@@ -127,8 +130,19 @@ constexpr int REV_XCB = 3;
 // for it) and idles half of phase E (wave 3 waits 9-11 % there).  So the row-block waves raise an LDS flag per row block
 // (flag_release / flag_wait, cbfssm_kernels.hpp) and the extra wave takes the first REV_XEARLY row blocks before that
 // barrier, the rest after it.
-constexpr int REV_XEARLY = 3;
+#ifndef CBF_REV_XEARLY
+#define CBF_REV_XEARLY 3
+#endif
+constexpr int REV_XEARLY = CBF_REV_XEARLY;
+#ifndef CBF_REV_XLATE
+#define CBF_REV_XLATE 1
+#endif
+constexpr int REV_XLATE = CBF_REV_XLATE;      // row blocks the extra wave takes behind barrier 5 (see the kernel)
+#ifdef CBF_NO_XW          // diagnostic builds: the seven-wave form
+constexpr bool rev_extra_wave(int, bool) { return false; }
+#else
 constexpr bool rev_extra_wave(int nblk, bool stash) { return nblk == 7 && !stash; }
+#endif
 
 // KD: k-steps of the products whose k index is the GP output dimension (mu Fm, s2 Fv): 4 in general, 2 when the launcher
 // knows Do <= 8 (the backward runs of the Sarcos class: dim_x - dim_y = 7) -- the other two would multiply zeros.
@@ -488,20 +502,38 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                     }
                 }
                 __syncthreads();                                     // 4: every A2bar row is written
-                // ... the rest inside phase F
+                // ... some inside phase F, the last REV_XLATE row blocks behind barrier 5 (the A2bar tile stays intact until
+                // phase E of the next step): phases G / D are mostly vector latency on the first four waves, this wave's
+                // SIMD partner (wave 3) carries little or none of it.  The accumulators are pinned in front of each
+                // barrier: left alone, the compiler sinks most of these MFMAs (they touch registers only) below BOTH
+                // barriers -- 34 of them ran after barrier 6, where the seven row-block waves had nothing but a copy
+                // to do and waited at the next barrier for this wave (phase B: 12 % of a step, measured per wave).
+                auto xblock = [&](int rb) {
+                    double abT[4];
 #pragma unroll
-                for (int rb = 0; rb < NBLK; ++rb) {
-                    if (rb >= REV_XEARLY) {
-                        double abT[4];
+                    for (int s = 0; s < 4; ++s) abT[s] = A2t[(16 * rb + nl) * PD + 4 * s + g];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) abT[s] = A2t[(16 * rb + nl) * PD + 4 * s + g];
+                    for (int cq = 0; cq < XCB; ++cq)
 #pragma unroll
-                        for (int cq = 0; cq < XCB; ++cq)
+                        for (int s = 0; s < 4; ++s) xacc[rb][cq] = CBF_MFMA(abT[s], kT[cq][s], xacc[rb][cq]);
+                };
+                auto xpin = [&](int rb) {
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) xacc[rb][cq] = CBF_MFMA(abT[s], kT[cq][s], xacc[rb][cq]);
-                    }
-                }
+                    for (int cq = 0; cq < XCB; ++cq) asm volatile("" : "+v"(xacc[rb][cq]));
+                };
+#pragma unroll
+                for (int rb = 0; rb < NBLK; ++rb)
+                    if (rb >= REV_XEARLY && rb < NBLK - REV_XLATE) xblock(rb);
+#pragma unroll
+                for (int rb = 0; rb < NBLK; ++rb)
+                    if (rb >= REV_XEARLY && rb < NBLK - REV_XLATE) xpin(rb);
                 __syncthreads();                                     // 5
+#pragma unroll
+                for (int rb = 0; rb < NBLK; ++rb)
+                    if (rb >= REV_XEARLY && rb >= NBLK - REV_XLATE) xblock(rb);
+#pragma unroll
+                for (int rb = 0; rb < NBLK; ++rb)
+                    if (rb >= REV_XEARLY && rb >= NBLK - REV_XLATE) xpin(rb);
                 __syncthreads();                                     // 6
             }
             double* slab = a.gpart + wg_linear * a.slab;
@@ -569,7 +601,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 #ifdef CBF_REV_STAMPS
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    CBF_STAMP_MARK0();
     for (int step = 0; step < nsteps; ++step) {
+        CBF_STAMP_MARK(11);
         const int t = t_of(step);
         const bool has_next = (step + 1 < nsteps);
         const int tn = has_next ? t_of(step + 1) : t;
@@ -582,6 +616,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         // ---- B with kept kernel tiles (KSV): the rows loaded a step ahead go to the LDS tile -- FIRST thing in the step:
         // vmcnt retires in order, so anything issued before this wait (the next step's inputs below) would be waited for too
         d4 kreg[RB];
+        CBF_STAMP_MARK0();
         if constexpr (KSV) {
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
@@ -590,9 +625,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 for (int r = 0; r < 4; ++r) Kt[(16 * rbs[i] + 4 * r + g) * PD + nl] = kreg[i][r];
             }
         }
+        CBF_STAMP_MARK(9);
         // next step's inputs: issued now, written to LDS at the end of phase E
         double hnext[QPW], auxn[AUXR];
         if (has_next) load_inputs(tn, tmn, hnext, auxn);
+        CBF_STAMP_MARK(10);
         // A2 rows of this wave, if the forward evaluation kept them (consumed after the second barrier)
         d4 a2[RB];
         if constexpr (KSV) {
@@ -651,6 +688,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
             }
         }
         }
+        CBF_STAMP_MARK(2);
         CBF_STAMP_BARRIER(1);
 
         // ---- C: A2 rows of this wave (only when the forward evaluation did not keep them)
@@ -1076,6 +1114,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         CBF_STAMP_MARK(3);
         tmod = tmn;
         CBF_STAMP_BARRIER(6);
+        CBF_STAMP_MARK0();
     }
 
     if (MODE == MODE_FWD) {
@@ -1177,7 +1216,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
             slab[SL::small + o + i] = double(st_c[i]);
             slab[SL::small + o + 7 + i] = double(st_w[i]);
         }
+#ifdef CBF_STAMP_MARKS_LAST
+        if (w == CBF_STAMP_WAVE) for (int i = 0; i < 12; ++i) slab[SL::small + 128 + i] = double(st_m[i]);   // sub-phase marks of that wave
+#else
         if (w == 0) for (int i = 0; i < 12; ++i) slab[SL::small + 128 + i] = double(st_m[i]);
+#endif
         if (w == 0) {
             // in-kernel clock: shader cycles per 100 MHz real-time tick (MI355X_MICROARCH.md, DVFS give-back item 6)
             slab[SL::small + 140] = double(__builtin_amdgcn_s_memtime() - clk0);

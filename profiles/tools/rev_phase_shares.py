@@ -36,8 +36,10 @@ for tag, slab, nwg, nstep_total in (('fwd-adjoint', eng.red[:eng.slab_f], ws.n_f
         for i in range(7):
             print('     %-32s compute %5.1f%%  barrier-wait %5.1f%%' % (names[i], 100 * c[i] / tot, 100 * wt[i] / tot))
         if wname == 'wave0':
-            marks = small[128:137]
-            mn = ['C loop (only without saved A2)', '-', '-', 'D epilogue adjoint (next step)', '-', 'E whole',
-                  'F loop(25)', 'F xp(8)', 'F transpose+gZ(8)']
-            for i in range(9):
+            marks = small[128:140]
+            mn = ['C loop (only without saved A2)', '-', 'B rest (after the input loads)', 'D epilogue adjoint (next step)', '-', 'E whole',
+                  'F loop(25)', 'F xp(8)', 'F transpose+gZ(8)', 'B saved rows -> LDS', 'B next inputs issued', 'loop back edge']
+            if os.environ.get('MARKS_LAST'):
+                print('        (sub-phase marks of the second recorded wave: -DCBF_STAMP_MARKS_LAST build)')
+            for i in range(12):
                 print('        sub %-20s %5.1f%%' % (mn[i], 100 * marks[i] / tot))
