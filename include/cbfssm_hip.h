@@ -154,8 +154,9 @@ int cbfssm_gp_predict_fullq_f64(const cbfssm_pack_layout* layout, const double* 
  *      h_all (2,T,N,dim_x-dim_y) or NULL: every step's output of both runs (kept for the adjoint)
  *      fmv_b (2,T,N,dim_x-dim_y,2) or NULL: every step's (fmean, fvar) after residual and process noise (kept for
  *      the adjoint, which then needs no recomputation of the predictive products)
- *      a2s_b (cbfssm_saved_a2_elems(p, L, 1) doubles) or NULL: every step's A2 = K_mm^-1 K_mn tiles, kept for the
- *      adjoint (which otherwise recomputes them: one M x M x 16 product per step less)
+ *      a2s_b (cbfssm_saved_a2_elems(p, L, 1) doubles) or NULL: every step's A2 = K_mm^-1 K_mn tiles -- and, for tile
+ *      heights up to seven row blocks (M <= 112), its kernel tile K_mn next to it -- kept for the adjoint (which
+ *      otherwise recomputes them: one M x M x 16 product, resp. the kernel tile's MFMAs and exponentials, per step less)
  *      ent_part (n_ent_part doubles): per-workgroup partial sums of 0.5*sum(log(2 pi e) + log fvar) over the
  *      written steps (cbfssm.py:154-156); their sum is `entropy` (cbfssm.py:99).
  *   cbfssm_backward_pass_partials(problem) gives n_ent_part.
@@ -171,14 +172,16 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
  *   y2 (T,N,dim_x-dim_y) from the backward pass, eps_f (T-1,N), var_x (dim_x), var_y (dim_x)
  *   -> x (T,N,dim_x)   [x[0] = y_tilde[0], cbfssm.py:168]
  *      fmv_f (T-1,N,dim_x,2) or NULL: every step's (fmean, fvar), kept for the adjoint
- *      a2s_f (cbfssm_saved_a2_elems(p, L, 0) doubles) or NULL: every step's A2 tiles, kept for the adjoint
+ *      a2s_f (cbfssm_saved_a2_elems(p, L, 0) doubles) or NULL: every step's A2 (and, M <= 112, kernel) tiles, kept
+ *      for the adjoint
  *      kl_part (n_kl_part doubles): per-workgroup partial sums of kl_reg (cbfssm.py:232-235); sum = kl_x.
  */
 int64_t cbfssm_forward_pass_partials(const cbfssm_problem* p);
 
-/* Doubles in the optional saved-A2 buffer of the backward (backward != 0) or forward pass: one M_pad x 16 tile per
- * step and 16-chain group, T*2 resp. T-1 steps (no reference counterpart: TF keeps its forward activations for
- * tf.gradients the same way, base_model.py:34-36). */
+/* Doubles in the optional saved-tile buffer of the backward (backward != 0) or forward pass: one record per step and
+ * 16-chain group, T*2 resp. T-1 steps; a record is the M_pad x 16 tile A2 and, when M <= 112, the kernel tile K_mn of
+ * the same shape behind it.  The buffer is opaque to the caller: the passes write it, their adjoints read it (no
+ * reference counterpart: TF keeps its forward activations for tf.gradients the same way, base_model.py:34-36). */
 int64_t cbfssm_saved_a2_elems(const cbfssm_problem* p, const cbfssm_pack_layout* layout, int backward);
 int cbfssm_forward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const double* pack_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
