@@ -30,7 +30,7 @@ def test_ragged_final_batch_shares_the_saved_tiles_at_c3_shape():
     l_full = float(st.step(*_batch(w, w.B, 0)))
     torch.cuda.synchronize()
     pool0, mem0 = eng.tile_pool.bytes(), torch.cuda.memory_allocated()
-    assert pool0 > 2 * 2 ** 30                                     # C3 keeps 3.4 GB of A2 tiles
+    assert pool0 > 2 * 2 ** 30                                     # C3 keeps 6.8 GB of [A2 | K] records (3.4 GB of A2 tiles alone)
     ws_full = eng.last_ws
     assert ws_full.a2s_f is not None and ws_full.a2s_b is not None
     with warnings.catch_warnings():
@@ -82,3 +82,28 @@ def test_shape_over_the_budget_falls_back_loudly(monkeypatch):
     for k in train.PARAM_NAMES:
         np.testing.assert_allclose(grads[k].cpu().numpy(), grads_r[k].cpu().numpy(), rtol=1e-9,
                                    atol=1e-12 * float(grads_r[k].abs().max()))
+
+
+@pytest.mark.parametrize('M', [20, 100])
+def test_kept_kernel_tiles_give_the_gradient_of_the_recomputing_adjoint(M, monkeypatch):
+    """Tile heights up to seven row blocks keep the kernel tile K = k(Z, x_t) of every step next to its A2 tile and the
+    adjoint reads it (rev_kernel<..., KSV>); with CBFSSM_NO_SAVE_K=1 the records hold the A2 tile only and the adjoint
+    rebuilds K from the saved trajectory.  Same inputs, same arithmetic for K: the two adjoints must agree to rounding."""
+    import ctypes as C
+    from cbfssm.hip import lib as _l
+    w = syn.tiny(M=M, dim_x=14, dim_u=7, dim_y=7, T=40, B=3, S=20, recog_len=8, k_factor=50., var_y=0.05 ** 2)
+    cfg = w.model_config()
+    p = {k: torch.tensor(v, device=DEV) for k, v in syn.perturb_params(syn.make_params(w, seed=3), scale=0.1).items()}
+    batch = _batch(w, w.B, 7)
+    e1 = train.HipElboGrad(cfg, DEV)
+    l1, g1, _ = e1.loss_and_grads(p, *batch)
+    g1 = {k: v.clone() for k, v in g1.items()}
+    n_kept = e1.tile_pool.bytes()
+    monkeypatch.setenv('CBFSSM_NO_SAVE_K', '1')
+    e2 = train.HipElboGrad(cfg, DEV)
+    l2, g2, _ = e2.loss_and_grads(p, *batch)
+    assert e2.tile_pool.bytes() * 2 == n_kept                      # the record is [A2 | K] resp. [A2]
+    assert float(l1) == float(l2)                                  # the forward evaluation is the same code
+    for k in g1:
+        a, b = g1[k].cpu().numpy(), g2[k].cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12 * max(np.abs(b).max(), 1e-300), err_msg=k)
