@@ -1217,6 +1217,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
         if constexpr (NC == 1) {
             double kr[RB][4];
             tile.phase1(xq, Kt, kr, w, l);
+            // The epilogue inputs prefetched above are made to land HERE, a phase after they were issued and in front of
+            // the tile stores of phase 2.  vmcnt retires in order and counts stores: left to the first use in phase 3, the
+            // wait the compiler can prove (a count that must also hold when no tiles are kept) waits in a train step for
+            // six of this step's eight tile stores to complete -- on the lanes that carry the step's serial chain.
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) asm volatile("" : "+v"(eps_t[qi]), "+v"(ytil[qi]), "+v"(hidn[qi]));
+#pragma unroll
+            for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+                for (int k2 = 0; k2 < AUXR; ++k2) asm volatile("" : "+v"(auxr[cb][k2]));
             if constexpr (TRI) {
                 // (the dense form's phase 2 writes the kernel tile next to its A2 rows; the two-triangular one does not see it)
                 if (a2o && tile.koff) {
