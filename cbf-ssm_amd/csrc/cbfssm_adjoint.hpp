@@ -385,7 +385,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) {
                 const int d = 4 * (w + qi * W) + g;
-                gy2in[qi] = act[qi] ? a.gy2[(int64_t(t) * N + c) * Do + d] : 0.0;
+                // (a branch, not a select: a select on the loaded value is an s_waitcnt right behind the load)
+                gy2in[qi] = 0.0;
+                if (act[qi]) gy2in[qi] = a.gy2[(int64_t(t) * N + c) * Do + d];
             }
         }
 #pragma unroll
@@ -774,10 +776,25 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 const double* mBp = (MULDS ? mul : a.rk.muB) + rbs[i] * 256 + l;
                 const double* sBp = a.rk.s2B + rbs[i] * 256 + l;
                 d4 T1 = {0, 0, 0, 0}, T2 = {0, 0, 0, 0};
+                if constexpr (MUPRE) {
 #pragma unroll
-                for (int s = 0; s < KD; ++s) {
-                    T1 = CBF_MFMA(MUPRE ? mBv[s] : mBp[s * 64], fmB[s], T1);
-                    T2 = CBF_MFMA(MUPRE ? sBv[s] : sBp[s * 64], fvB[s], T2);
+                    for (int s = 0; s < KD; ++s) {
+                        T1 = CBF_MFMA(mBv[s], fmB[s], T1);
+                        T2 = CBF_MFMA(sBv[s], fvB[s], T2);
+                    }
+                } else {
+                    // the operand rows of this row block: ALL issued, then one wait (pinned) -- left at their MFMAs the
+                    // compiler emits load, s_waitcnt vmcnt(0), MFMA eight times over: eight L1 / L2 round trips in a row
+                    double mv[KD], sv[KD];
+#pragma unroll
+                    for (int s = 0; s < KD; ++s) { mv[s] = mBp[s * 64]; sv[s] = sBp[s * 64]; }
+#pragma unroll
+                    for (int s = 0; s < KD; ++s) asm volatile("" : "+v"(mv[s]), "+v"(sv[s]));
+#pragma unroll
+                    for (int s = 0; s < KD; ++s) {
+                        T1 = CBF_MFMA(mv[s], fmB[s], T1);
+                        T2 = CBF_MFMA(sv[s], fvB[s], T2);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a2bar[i][r] = T1[r] + 2.0 * a2[i][r] * T2[r] - kreg[i][r] * fvsum;
