@@ -79,6 +79,25 @@ def test_train_step_decreases_loss_and_matches_tf_adam_rule():
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize('M', [70, 110])
+def test_grad_seven_row_block_tiles_other_heights(M):
+    """The seven-row-block tile (M = 65..112) away from the Sarcos height: M = 70 (18 k-steps: the general loop of the
+    K^-1 A2bar product, untrimmed pass tiles) and M = 110 (the K^-1 image no longer fits the LDS next to the adjoint's tiles:
+    streamed from L2) -- both with kept kernel tiles -- against reverse-mode autodiff of the restatement."""
+    from oracle import cbfssm_torch_ref as tref
+    w = syn.tiny(M=M, dim_x=14, dim_u=7, dim_y=7, T=11, B=2, S=12, recog_len=3, k_factor=50., var_y=0.05 ** 2,
+                 loss_factors=(3., 0.7))
+    cfg = w.model_config()
+    p = syn.perturb_params(syn.make_params(w, seed=2), scale=0.1)
+    u, y = syn.make_inputs(w)
+    noise = syn.make_noise(w)
+    eng = train.HipElboGrad(cfg, DEV)
+    loss, grads, _ = eng.loss_and_grads({k: torch.tensor(v, device=DEV) for k, v in p.items()}, u, y, noise)
+    scal, gref = tref.loss_and_grads(cfg, p, u, y, noise, True)
+    assert float(loss) == pytest.approx(scal['loss'], rel=1e-9)
+    _check(grads, gref)
+
+
 @pytest.mark.parametrize('kw', [
     dict(M=20, T=13, B=2, S=8),
     dict(M=130, dim_x=9, dim_u=3, dim_y=2, T=14, B=2, S=9, recog_len=3, k_factor=20.),       # stash mode: dense K^-1 adjoint
