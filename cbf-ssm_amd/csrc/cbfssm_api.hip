@@ -79,7 +79,10 @@ struct PrepArgs2 {
 
 #define PREP_NT 1024
 #define PREP_NB 32
-#define PREP_LDS_MAX_M 140   // (M | 1) * M doubles must fit the 160 KiB LDS next to the small arrays
+#define PREP_LDS_MAX_M 140
+#ifndef CBF_REFINE_COND
+#define CBF_REFINE_COND 1e4   // infinity-norm condition number of K_mm + jitter I above which G = L^-T gets its Newton step
+#endif   // (M | 1) * M doubles must fit the 160 KiB LDS next to the small arrays
 
 // One workgroup per GPModel (blockIdx.x).  The working matrix W (row stride LD, odd) starts as
 //   lower triangle + diagonal: K_mm + jitter I ;  strict upper triangle: 0 (the off-diagonal of the bordering identity)
@@ -274,15 +277,17 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
     __syncthreads();
     if (a.info_out && tid == 0) a.info_out[0] = double(s_info);
     if (!a.Kinv) return;
-    // scale the upper part in place (own element only), then K^-1 = G G^T, G = L^-T upper triangular
+    // scale both halves in place (own element only): lower part L (the values just written to Lout), upper part and
+    // diagonal G = L^-T; then K^-1 = G G^T
     for (int i = ty; i < M; i += 32)
-        for (int k = i + tx; k < M; k += 32) {
+        for (int k = tx; k < M; k += 32) {
             const double sp = sqrt(piv[k]);
-            Wm[i * LD + k] = (k > i) ? Wm[i * LD + k] / sp : 1.0 / sp;    // diagonal now holds G[i][i]
+            const double w = Wm[i * LD + k];
+            Wm[i * LD + k] = (k > i) ? w / sp : ((k == i) ? 1.0 / sp : w / sp);    // diagonal now holds G[i][i]
         }
     __syncthreads();
     // K^-1[i][k] = sum_{q >= max(i,k)} G[i][q] G[k][q]: 16 x 16 tiles of the lower triangle on the f64 MFMA units
-    {
+    auto kinv_product = [&]() {
         int cnt = 0;
         for (int ib = 0; ib < NBT; ++ib) {
             for (int kb = 0; kb <= ib; ++kb, ++cnt) {
@@ -308,8 +313,89 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
                 }
             }
         }
-    }
+    };
+    kinv_product();
     __syncthreads();
+    // infinity-norm condition number of K_mm + jitter I (row sums of |K| and |K^-1|): what the caller's choice between
+    // the dense and the two-triangular GP form goes by, and what decides about the refinement of G below
+    __shared__ double cn[2][PREP_NT / 64];
+    __shared__ double s_cond;
+    {
+        double kn = 0.0, kin = 0.0;
+        for (int i = wv; i < M; i += NWAVE) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = l; k < M; k += 64) {
+                const double kv = a.Kin ? a.Kin[i * M + k] : a.Kmm[i * M + k];
+                s1 += fabs(kv) + (k == i ? a.jitter : 0.0);
+                s2 += fabs(a.Kinv[i * M + k]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            kn = fmax(kn, s1);
+            kin = fmax(kin, s2);
+        }
+        if (l == 0) { cn[0][wv] = kn; cn[1][wv] = kin; }
+        __syncthreads();
+        if (tid == 0) {
+            double c0 = 0.0, c1 = 0.0;
+            for (int i = 0; i < NWAVE; ++i) { c0 = fmax(c0, cn[0][i]); c1 = fmax(c1, cn[1][i]); }
+            s_cond = c0 * c1;
+        }
+        __syncthreads();
+    }
+    // ---- refinement of G = L^-T on ill-conditioned K_mm.  The elimination gives W = L^-1 = G^T column by column with a
+    // small RIGHT residual I - L W (each column is a backward-stable substitution), but the kernels multiply by W from
+    // the left (A = W k, gp_tf.py:137; A2 = W^T A, gp_tf.py:145) where the reference back-substitutes, and W L - I is of
+    // order cond(L) eps: at cond(K_mm) 2e9 that put the predictive mean of a 250-step recurrence 5e-5 from the oracle, ten
+    // times what two LAPACK codings differ by.  One Newton step W <- W + W (I - L W) with the residual accumulated in
+    // doubled precision (compensated dot products: exact products by FMA, two-sum accumulation) squares the residual
+    // (1e-11 -> 1e-22): W becomes the correctly rounded inverse of the L written above, and W k is then as accurate
+    // as the substitution.  Runs above CBF_REFINE_COND only (a uniform branch on the measured condition number).
+    if (s_cond > CBF_REFINE_COND && s_info == 0 && a.Bp) {
+        double* Rg = a.Kinv;        // scratch until K^-1 is rebuilt: lower + diagonal = R, strict upper = the correction of G
+        double* cdiag = a.Bp;       // (diagonal of the correction: the image section is written further down)
+        {
+#pragma clang fp contract(off)
+            for (int idx = tid; idx < M * M; idx += PREP_NT) {
+                const int i = idx / M, j = idx - i * M;
+                if (j > i) continue;
+                // R[i][j] = delta_ij - sum_{k=j..i} L[i][k] W[k][j],  W[k][j] = G[j][k],  L[i][i] = sqrt(piv_i)
+                double s = (i == j) ? 1.0 : 0.0, c = 0.0;
+                for (int k = j; k <= i; ++k) {
+                    const double lv = (k == i) ? sqrt(piv[i]) : Wm[i * LD + k];
+                    const double gv = Wm[j * LD + k];
+                    const double p = -(lv * gv);
+                    const double e = __builtin_fma(-lv, gv, -p);     // exact: lv gv = -(p + e)
+                    const double t = s + p;
+                    const double z = t - s;
+                    c += ((s - (t - z)) + (p - z)) + e;               // two-sum error of s + p, plus the product's
+                    s = t;
+                }
+                const double r = s + c;
+                Rg[i * M + j] = r;
+            }
+        }
+        __syncthreads();
+        // correction of G: C[j][k] = sum_{i=j..k} R[i][j] G[i][k]   (W + W R, transposed)
+        for (int idx = tid; idx < M * M; idx += PREP_NT) {
+            const int j = idx / M, k = idx - j * M;
+            if (k < j) continue;
+            double cs = 0.0;
+            for (int i = j; i <= k; ++i) cs += Rg[i * M + j] * Wm[i * LD + k];
+            if (k == j) cdiag[j] = cs; else Rg[j * M + k] = cs;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < M * M; idx += PREP_NT) {
+            const int j = idx / M, k = idx - j * M;
+            if (k < j) continue;
+            const double gn = Wm[j * LD + k] + ((k == j) ? cdiag[j] : Rg[j * M + k]);
+            Wm[j * LD + k] = gn;
+            if (a.Gout) a.Gout[j * M + k] = gn;
+        }
+        __syncthreads();
+        kinv_product();
+        __syncthreads();
+    }
 #ifdef CBF_PREP_STAMPS
     long long tk2 = clock64();
 #endif
@@ -337,22 +423,6 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
         const int row = 16 * rb + (l & 15), col = 4 * s + (l >> 4);
         a.Zp[i] = (row < M && col < D) ? a.Zs[row * D + col] : 0.0;
     }
-    // infinity-norm condition number of K_mm + jitter I (row sums of |K| and |K^-1|): what the caller's choice between
-    // the dense and the two-triangular GP form goes by
-    double kn = 0.0, kin = 0.0;
-    for (int i = wv; i < M; i += NWAVE) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = l; k < M; k += 64) {
-            s1 += fabs(a.Kmm[i * M + k]) + (k == i ? a.jitter : 0.0);
-            s2 += fabs(Cm[i * M + k]);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        kn = fmax(kn, s1);
-        kin = fmax(kin, s2);
-    }
-    __shared__ double cn[2][PREP_NT / 64];
-    if (l == 0) { cn[0][wv] = kn; cn[1][wv] = kin; }
     const double logvar = log(var);
     for (int m = tid; m < Mp; m += PREP_NT) a.cz[m] = (m < M) ? (-0.5 * Xs[m] + logvar) : -1e30;
     for (int i = tid; i < NBLK * 4 * 64; i += PREP_NT) {
@@ -403,9 +473,7 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
         a.scal[CBFSSM_SCAL_KLZ] = 0.5 * (tot + double(Do) * (logdet - double(M)));
         a.scal[CBFSSM_SCAL_INFO] = double(s_info);
         for (int i = 4; i < CBFSSM_SCAL_COUNT; ++i) a.scal[i] = 0.0;
-        double c0 = 0.0, c1 = 0.0;
-        for (int i = 0; i < NWAVE; ++i) { c0 = fmax(c0, cn[0][i]); c1 = fmax(c1, cn[1][i]); }
-        a.scal[CBFSSM_SCAL_COND] = c0 * c1;
+        a.scal[CBFSSM_SCAL_COND] = s_cond;
         a.scal[CBFSSM_SCAL_JITTER] = a.jitter;
 #ifdef CBF_PREP_STAMPS
         a.scal[8] = double(tk_pan); a.scal[9] = double(tk_upd); a.scal[10] = double(tk2 - tk1); a.scal[11] = double(clock64() - tk2);

@@ -11,8 +11,10 @@ What 1e-5 can mean in (b).  The reference's own arithmetic (two triangular solve
 gp_tf.py:137-145) carries errors of order cond * eps into fmean and the recurrence amplifies them over T steps; two
 float64 codings of that SAME algorithm on different BLAS back-ends (the numpy/LAPACK oracle and the PyTorch
 restatement, both CPU) therefore differ by a `floor` that is measured here next to every HIP number.  The tests ask
-HIP-vs-oracle <= 1e-5 wherever floor <= 1e-6 and <= 20 x floor above (nothing can be closer to the reference than the
-reference is to itself).  Every achieved error is printed and collected in gpurun_out/parity_report.json.
+HIP-vs-oracle <= 1e-5 wherever floor <= 1e-6 and <= FLOOR_MULT (3) x floor above (nothing can be closer to the reference
+than the reference is to itself; round 2 needed 20 x at cond 2e9 -- the library multiplied by an explicitly formed L^-1
+whose LEFT residual was of order cond(L) eps; the prepare kernel now refines it in doubled precision, csrc/cbfssm_api.hip).
+Every achieved error is printed and collected in gpurun_out/parity_report.json.
 """
 import dataclasses
 import json
@@ -28,6 +30,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 DEV = 'cuda:0'
 BOUND = 1e-5                                   # north_star: relative, on the ELBO and the predictive mean/variance
+FLOOR_MULT = 3.0                               # allowed multiple of the CPU-vs-CPU reproducibility floor where it exceeds 1e-6
 REPORT = {}
 
 
@@ -166,8 +169,40 @@ def test_trained_like_sweep_full_recurrence(ls_mult):
     _report('sweep_C3/ls_x%d' % ls_mult, {'cond_f': cond_f, 'cond_b': cond_b, 'hip': e, 'floor': floor,
                                           'gp_form': eng.gp_form() if hasattr(eng, 'gp_form') else 'dense'})
     for k in ('loss', 'pred_mean', 'pred_var'):
-        lim = BOUND if floor[k] <= 1e-6 else 20.0 * floor[k]
+        lim = BOUND if floor[k] <= 1e-6 else max(BOUND, FLOOR_MULT * floor[k])
         assert e[k] <= lim, (k, e[k], lim, floor[k])
+
+
+@pytest.mark.parametrize('ls_mult', [128, 256])
+def test_refined_inverse_factor_left_residual(ls_mult):
+    """The pack's G = L^-T (what the two-triangular kernels multiply by, gp_tf.py:137,145 being two substitutions in the
+    reference) after the prepare kernel's Newton step in doubled precision: W = G^T must invert the pack's own L from the
+    LEFT to rounding level, |W L - I| <= 4 eps max|W| max|L| -- a column-by-column substitution (what the elimination
+    computes, reproduced here with scipy on the same L) leaves 20 x that at cond 2e9."""
+    import scipy.linalg as sla
+    w = dataclasses.replace(syn.WORKLOADS['C3'], B=2)
+    p = syn.trained_like_params(w, ls_mult=float(ls_mult), zeta_mean=0.1)
+    eng = ops.HipElbo(w.model_config(), DEV)
+    eng.prepare(p)
+    LD = np.longdouble
+    eps = np.finfo(np.float64).eps
+    for pk in (eng.pack_f, eng.pack_b):
+        L = pk.L.cpu().numpy()
+        W = pk.section('Linvt', (pk.M, pk.M)).cpu().numpy().T
+        eye = np.eye(pk.M)
+        left = float(np.abs(W.astype(LD) @ L.astype(LD) - eye).max())
+        right = float(np.abs(L.astype(LD) @ W.astype(LD) - eye).max())
+        W0 = sla.solve_triangular(L, eye, lower=True)
+        left0 = float(np.abs(W0.astype(LD) @ L.astype(LD) - eye).max())
+        lim = 4.0 * eps * np.abs(W).max() * np.abs(L).max()
+        print('\nls x%d M=%d: |W L - I| %.2e (substitution on the same L: %.2e), |L W - I| %.2e, bound %.2e'
+              % (ls_mult, pk.M, left, left0, right, lim))
+        _report('refine/ls_x%d_Do%d' % (ls_mult, pk.Do), {'left': left, 'left_substitution': left0, 'right': right})
+        assert left <= lim and right <= lim and left <= 0.25 * left0, (left, left0, right, lim)
+        # K^-1 of the pack is G G^T of the refined factor
+        Kinv = pk.Kinv.cpu().numpy()
+        ref = (W.T.astype(LD) @ W.astype(LD)).astype(np.float64)
+        assert np.abs(Kinv - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize('M,D,Do,ls,spread', [(100, 21, 14, 8., 2.0), (100, 21, 14, 8., 1.0), (100, 21, 14, 16., 1.0),
