@@ -123,9 +123,77 @@ def main_half():
     print('half_tiny', os.path.getsize(path) // 1024, 'KiB', 'loss', blob['c1_loss'])
 
 
+# Trained-like, ill-conditioned parameters (cbfssm.synthetic.trained_like_params) through the full C3 recurrence: the
+# oracle's outputs, the reproducibility floor of the reference formulation (numpy/LAPACK oracle vs the PyTorch-CPU
+# restatement of the same two triangular solves) and reverse-mode gradients of the restatement.  These take minutes of
+# CPU time; the GPU tests read them from tests/golden/trained_*.npz (inputs are regenerated from the seeds; a checksum of
+# the parameters guards the generators).
+TRAINED_SWEEP = [8, 16, 32, 64, 128, 256]
+TRAINED_GRADS = [(64, 'C3', 250), (32, 'C4', 60)]
+
+
+def trained_case(base, ls_mult, T=None):
+    import dataclasses
+    kw = dict(B=2)
+    if T is not None:
+        kw['T'] = T
+    w = dataclasses.replace(syn.WORKLOADS[base], **kw)
+    p = syn.trained_like_params(w, ls_mult=float(ls_mult), zeta_mean=0.1)
+    u, y = syn.make_inputs(w, seed=0)
+    noise = syn.make_noise(w, seed=2)
+    return w, p, u, y, noise
+
+
+def param_checksum(p):
+    return float(sum(float(np.sum(v * np.cos(np.arange(v.size).reshape(v.shape)))) for _, v in sorted(p.items())))
+
+
+def main_trained():
+    import torch
+    out_dir = os.path.join(ROOT, 'tests', 'golden')
+    blob = {'sweep': np.asarray(TRAINED_SWEEP)}
+    tsel = None
+    for m in TRAINED_SWEEP:
+        w, p, u, y, noise = trained_case('C3', m)
+        cfg = w.model_config()
+        if tsel is None:
+            tsel = np.unique(np.concatenate((np.arange(0, w.T, T_STRIDE), [w.T - 1])))
+            blob['t_sel'] = tsel
+        ref = orc.elbo_step(cfg, p, u, y, noise, True)
+        with torch.no_grad():
+            o = tref.elbo_step(cfg, {k: torch.tensor(v) for k, v in p.items()}, torch.tensor(u), torch.tensor(y),
+                               {k: torch.tensor(v) for k, v in noise.items()}, True, want_pred=True)
+        tag = 'x%d_' % m
+        for k in ('loss', 'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b', 'pred_mean', 'pred_var'):
+            blob[tag + k] = np.asarray(ref[k])
+        blob[tag + 'x_final_sel'] = np.asarray(ref['x_final'][:, tsel])
+        blob[tag + 'y2_sel'] = np.asarray(ref['y_tilde'][:, tsel][..., w.dim_y:])
+        blob[tag + 'floor_loss'] = abs(float(o['loss']) - float(ref['loss'])) / abs(float(ref['loss']))
+        blob[tag + 'floor_pred_mean'] = np.abs(o['pred_mean'].numpy() - ref['pred_mean']).max() / np.abs(ref['pred_mean']).max()
+        blob[tag + 'floor_pred_var'] = (np.abs(o['pred_var'].numpy() - ref['pred_var']) / np.abs(ref['pred_var'])).max()
+        blob[tag + 'cond_f'] = syn.kmm_condition(p, 'f')
+        blob[tag + 'cond_b'] = syn.kmm_condition(p, 'b')
+        blob[tag + 'param_checksum'] = param_checksum(p)
+        print('sweep x%d' % m, 'cond %.1e' % blob[tag + 'cond_f'], 'floor', blob[tag + 'floor_loss'],
+              blob[tag + 'floor_pred_mean'], blob[tag + 'floor_pred_var'], flush=True)
+    for m, base, T in TRAINED_GRADS:
+        w, p, u, y, noise = trained_case(base, m, T)
+        scal, gref = tref.loss_and_grads(w.model_config(), p, u, y, noise, True)
+        tag = 'g_%s_x%d_' % (base, m)
+        blob[tag + 'loss'] = scal['loss']
+        blob[tag + 'param_checksum'] = param_checksum(p)
+        blob.update({tag + 'grad_' + k: g for k, g in gref.items()})
+        print('grad', base, m, T, scal['loss'], flush=True)
+    path = os.path.join(out_dir, 'trained_C3.npz')
+    np.savez_compressed(path, **blob)
+    print('trained_C3', os.path.getsize(path) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'full':
         main_full()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'trained':
+        main_trained()
     else:
         main()
         main_half()

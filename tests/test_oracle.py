@@ -273,3 +273,23 @@ def test_prssm_is_half_without_conditioning_and_fd():
             fd = (float(tref.prssm_loss_and_grads(cfg, pp, u, y, noise)[0]['loss'])
                   - float(tref.prssm_loss_and_grads(cfg, pm, u, y, noise)[0]['loss'])) / (2 * h)
             assert grads[name].reshape(-1)[idx] == pytest.approx(fd, rel=5e-5, abs=1e-6), (name, idx)
+
+
+def test_trained_like_fixture_is_this_oracles_output():
+    """tests/golden/trained_C3.npz (read by the GPU parity tests instead of recomputing minutes of oracle time): one sweep
+    point re-derived here -- inputs from the seeds, outputs from the numpy oracle -- must reproduce the fixture."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import make_golden as mg
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trained_C3.npz'))
+    m = 16
+    w, p, u, y, noise = mg.trained_case('C3', m)
+    tag = 'x%d_' % m
+    assert abs(mg.param_checksum(p) - float(z[tag + 'param_checksum'])) <= 1e-9 * abs(float(z[tag + 'param_checksum']))
+    ref = orc.elbo_step(w.model_config(), p, u, y, noise, True)
+    assert abs(ref['loss'] - float(z[tag + 'loss'])) <= 1e-12 * abs(ref['loss'])
+    np.testing.assert_allclose(ref['pred_mean'], z[tag + 'pred_mean'], rtol=0, atol=1e-9 * np.abs(ref['pred_mean']).max())
+    np.testing.assert_allclose(ref['pred_var'], z[tag + 'pred_var'], rtol=1e-8)
+    np.testing.assert_allclose(ref['x_final'][:, z['t_sel']], z[tag + 'x_final_sel'], rtol=0,
+                               atol=1e-9 * np.abs(ref['x_final']).max())
