@@ -59,14 +59,19 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(w, mode='eval', full=False):
+def cpu_baseline(w, mode='eval', policy='auto'):
     """The op-for-op PyTorch-CPU float64 restatement (oracle/cbfssm_torch_ref.py) of the reference's TF-1.8 graph, timed
-    on this box's host cores (BASELINE.md section 2 / SURVEY.md section 8d) on a BOUNDED sample of the same workload:
-    every size as configured (recog_len too), only T cut to 64 steps (191 of 3T-1 GP calls; the op sequence is exactly
-    linear in the number of GP calls, which the T = 8 timing next to it checks), scaled to the full T.  Two thread
-    settings: the reference's own session config (5 intra-op / 10 inter-op threads, training/trainer.py:22-26) and all
-    cores.  `full=True` (bench.py --cpu-baseline full) times the full-T step once instead (about 25-60 s per step and
-    30 GB of autograd state at C3).  mode=train times loss + reverse-mode gradient (what minimize() executes)."""
+    on this box's host cores (BASELINE.md section 2 / SURVEY.md section 8d), every size as configured (recog_len too).
+    Two thread settings: the reference's own session config (5 intra-op / 10 inter-op threads, training/trainer.py:22-26)
+    and all cores the job may use.
+
+    policy 'auto' (default): samples at T = 8 and T = 64 first (they are the warm-ups and show how the time per GP call
+    converges); when the T = 64 sample predicts at most CBFSSM_CPU_FULL_LIMIT (90) seconds per full step the FULL-T step is
+    timed -- median of three on all cores, once with the reference session config -- and `extrapolated` is false (C3:
+    about a minute of CPU work in all; the autograd state of a full C3 train step is about 30 GB of host memory).
+    Otherwise a T = 128 sample is added and the largest sample is scaled linearly in the number of GP calls.
+    'sample': the T = 64 sample only, scaled.  'full': full T whatever it costs, median of five after two warm-ups
+    (BASELINE.md section 2).  mode=train times loss + reverse-mode gradient (what minimize() executes)."""
     from cbfssm import synthetic as syn
     from oracle import cbfssm_torch_ref as tref
     import dataclasses
@@ -99,28 +104,49 @@ def cpu_baseline(w, mode='eval', full=False):
         return ts
 
     calls = lambda T: 3 * T - 1
-    T_s = w.T if full else min(w.T, 64)
+    per_call = {}                                            # seconds per GP call on all cores, by sample length
     T_0 = min(w.T, 8)
-    t8 = timed(T_0, ncores, 3)                               # warm-up + the linearity check's short sample
-    t8 = float(np.median(t8[1:]))
-    reps = 1 if full else 2                                  # (the first run of a size pays the allocator's first touch)
-    t_all = float(min(timed(T_s, ncores, reps)))
-    t_ref = float(min(timed(T_s, 5, reps)))
+    per_call[T_0] = float(np.median(timed(T_0, ncores, 3)[1:])) / calls(T_0)
+    T_1 = min(w.T, 64)
+    t64_all = float(min(timed(T_1, ncores, 2)))              # (the first run of a size pays the allocator's first touch)
+    per_call[T_1] = t64_all / calls(T_1)
+    predicted = per_call[T_1] * calls(w.T)
+    limit = float(os.environ.get('CBFSSM_CPU_FULL_LIMIT', '90'))
+    if policy == 'full' or (policy == 'auto' and predicted <= limit):
+        T_s = w.T
+        if policy == 'full':
+            reps_all, stat = 7, 'median of 5 after 2 warm-ups'
+            ts = timed(T_s, ncores, reps_all)[2:]
+        else:
+            reps_all, stat = 3, 'median of 3 (the T = 8 and T = 64 samples ran before as warm-ups)'
+            ts = timed(T_s, ncores, reps_all)
+        t_all = float(np.median(ts))
+        t_ref = float(min(timed(T_s, 5, 3 if policy == 'full' else 1)))
+    elif policy == 'sample' or T_1 == w.T:
+        T_s, stat = T_1, 'faster of 2'
+        t_all = t64_all
+        t_ref = float(min(timed(T_s, 5, 2)))
+    else:
+        T_s, stat = min(w.T, 128), 'faster of 2'
+        t_all = float(min(timed(T_s, ncores, 2)))
+        t_ref = float(min(timed(T_s, 5, 1)))
+    per_call[T_s] = t_all / calls(T_s)
     scale = calls(w.T) / calls(T_s)
-    per_call_ratio = (t_all / calls(T_s)) / (t8 / calls(T_0))
     best = min(t_all, t_ref) * scale
+    conv = {('T%d' % k): v for k, v in sorted(per_call.items())}
     return {'value': 1.0 / best, 'unit': 'steps/s', 'cores': host_cores, 'cores_usable': usable, 'cpu_model': _cpu_model(),
             'kind': 'port',
             'threads': {'all_cores': {'intra_op': ncores, 'seconds_per_step': t_all * scale},
                         'reference_session_config': {'intra_op': 5, 'inter_op': 10, 'seconds_per_step': t_ref * scale}},
             'sample_T': T_s, 'sample_gp_calls': calls(T_s), 'full_gp_calls': calls(w.T), 'extrapolated': T_s != w.T,
-            'linearity_T%d_vs_T%d_per_call' % (T_s, T_0): per_call_ratio,
+            'seconds_per_gp_call_all_cores': conv, 'statistic': stat,
             'sample': '%s step of %s, every size as configured (M=%d B=%d S=%d recog_len=%d), T = %d of %d (%d of %d GP '
-                      'calls): %.2f s on %d threads (the job\'s share of the host\'s cores), %.2f s with the reference session config (5 intra-op / 10 '
-                      'inter-op threads)%s; time per GP call at T=%d is %.2fx that at T=%d; PyTorch-CPU float64 '
-                      'restatement of the TF-1.8 op sequence%s; value = the faster of the two settings'
-                      % (mode, w.name, w.M, w.B, w.S, w.recog_len, T_s, w.T, calls(T_s), calls(w.T), t_all, ncores, t_ref,
-                         '' if T_s == w.T else ', scaled linearly to T=%d' % w.T, T_s, per_call_ratio, T_0,
+                      'calls): %.2f s on %d threads (the job\'s share of the host\'s cores; %s), %.2f s with the reference '
+                      'session config (5 intra-op / 10 inter-op threads)%s; seconds per GP call on all cores at T = %s: %s; '
+                      'PyTorch-CPU float64 restatement of the TF-1.8 op sequence%s; value = the faster of the two settings'
+                      % (mode, w.name, w.M, w.B, w.S, w.recog_len, T_s, w.T, calls(T_s), calls(w.T), t_all, ncores, stat, t_ref,
+                         '' if T_s == w.T else ', scaled linearly to T=%d' % w.T,
+                         ' / '.join(str(k) for k in sorted(per_call)), ' / '.join('%.4f' % per_call[k] for k in sorted(per_call)),
                          ' + reverse-mode autodiff' if mode == 'train' else '')}
 
 
@@ -134,7 +160,11 @@ def main():
                          'config of BASELINE.json, 256 sequences per GPU, when --gpus > 1)')
     ap.add_argument('--mode', default='auto', choices=['auto', 'eval', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline', default='sample', choices=['sample', 'full'])
+    ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'sample', 'full'])
+    ap.add_argument('--params', default='init', choices=['init', 'trained'],
+                    help='init: run-script initial values (cond(K_mm) 1..700, dense GP form).  trained: the trained-like '
+                         'family of the parity sweep (cbfssm.synthetic.trained_like_params, lengthscales x 32, inducing means '
+                         '0.1: cond 2e6, the two-triangular GP form a trained model runs in)')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'],
                     help='float32: the float32-arithmetic forward evaluation (eval mode only; NOT the headline: the '
                          'reference computes in float64)')
@@ -183,7 +213,11 @@ def main():
     g.manual_seed(1234 + rank)
     u = torch.randn(w.B, w.T, w.dim_u, dtype=torch.float64, device=dev, generator=g)
     y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=dev, generator=g)
-    params = {k: torch.tensor(v, device=dev) for k, v in syn.make_params(w, seed=1).items()}
+    if args.params == 'trained':
+        p_np = syn.trained_like_params(w, ls_mult=32.0, zeta_mean=0.1)
+    else:
+        p_np = syn.make_params(w, seed=1)
+    params = {k: torch.tensor(v, device=dev) for k, v in p_np.items()}
     N = w.N
     # fresh noise every step (the reference draws it inside the graph); the draw for step k+1 runs on a side stream
     # while step k computes
@@ -234,6 +268,40 @@ def main():
     loss = float(out[6]) if mode == 'eval' else float(out)
     assert np.isfinite(loss), 'non-finite loss'
 
+    # ---- the step's ONE collective, timed by itself on every rank (all ranks take part; rank 0 reports): HIP events on
+    # the launch stream for RCCL, wall clock around a synchronised call for the gloo rehearsal
+    coll = None
+    if world > 1:
+        from cbfssm.hip.dist_utils import all_reduce_sum
+        nel = int(stepper.engine.red.numel()) if mode == 'train' else 3
+        buf = torch.ones(nel, dtype=torch.float64, device=dev)
+        reps = 20
+        for _ in range(3):
+            all_reduce_sum(buf, dist)
+            buf.fill_(1.0)
+        sync()
+        if dist.get_backend() == 'nccl':
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                all_reduce_sum(buf, dist)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+        else:
+            t0c = time.perf_counter()
+            for _ in range(reps):
+                all_reduce_sum(buf, dist)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0c) * 1e3 / reps
+        # 1.0 summed over `world` ranks, `reps` + 0 times since the last fill: world ** reps (exact in float64 up to 2^53)
+        expect = float(world) ** reps
+        ok = bool(abs(float(buf[0]) / expect - 1.0) < 1e-12) if expect < 2.0 ** 53 else None
+        coll = {'op': 'all_reduce(sum)', 'backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ''),
+                'ranks': dist.get_world_size(), 'bytes': nel * 8, 'ms': ms, 'per_step': 1, 'sum_checked': ok,
+                'timing': 'HIP events, %d back-to-back calls' % reps if dist.get_backend() == 'nccl' else 'wall clock'}
+        sync()
+
     # ---- per-kernel timing of the time-loop kernels with HIP events on the launch stream
     roof = None
     if rank == 0 and args.dtype == 'float32':
@@ -257,13 +325,28 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) * 1e-3 / reps
 
-        if mode == 'train' and not stepper.engine.stash:
+        stash = (mode == 'train') and stepper.engine.stash
+        stash_ms = None
+        if mode == 'train':
             eng2 = stepper.engine
             group, eng2.dist = eng2.dist, None     # rank-local from here on: the other ranks do not take part
             try:
                 eng2.loss_and_grads(stepper.params, u, y, noise)      # fills the saved trajectories
+                if stash:
+                    # stash mode (M > 112): the adjoint is a schedule of time-chunked launches + contractions
+                    # (hip/train.py:_adjoint_stash).  Run it with every launch bracketed by HIP events on ONE stream and
+                    # sum per kind: each kernel's own time, nothing overlapping it
+                    for _ in range(3):
+                        eng2._prof = []
+                        eng2.loss_and_grads(stepper.params, u, y, noise)
+                        torch.cuda.synchronize()
+                        stash_ms, stash_n = {}, {}
+                        for kind, e0, e1 in eng2._prof:
+                            stash_ms[kind] = stash_ms.get(kind, 0.0) + e0.elapsed_time(e1)
+                            stash_n[kind] = stash_n.get(kind, 0) + 1
             finally:
                 eng2.dist = group
+                eng2._prof = None
             ws = eng2.last_ws
             cst = eng2._constrained({k: v for k, v in stepper.params.items()})
             var_x, var_y = cst['var_x'], cst['var_y']
@@ -293,7 +376,20 @@ def main():
         k_bwd(); k_fwd()
         kern['backward_pass'] = (time_kernel(k_bwd), 2.0 * w.T * N * F(w.M, w.D, w.dim_out_b))
         kern['forward_pass'] = (time_kernel(k_fwd), 1.0 * (w.T - 1) * N * F(w.M, w.D, w.dim_x))
-        if mode == 'train' and not stepper.engine.stash:
+        # adjoint of one GP evaluation: the reverse sweep costs 2F (K^-1 A2bar and the A2bar K^T outer product);
+        # without the saved A2 tiles the kernel also recomputes the evaluation itself (+F)  
+        fa = 2.0 if (mode == 'train' and ws.a2s_b is not None) else 3.0
+        pts_f, pts_b = 1.0 * (w.T - 1) * N, 2.0 * w.T * N          # GP point evaluations per launch
+        launches = None
+        if stash:
+            # the outer product A2bar K^T (2 M^2 flops per GP point) is not in the adjoint kernels here: they write its
+            # operand images and cbfssm_stash_contract_f64 does it -- priced where it runs
+            outer = 2.0 * w.M * w.M
+            kern['forward_pass_adjoint'] = (stash_ms['forward_pass_adjoint'] * 1e-3, pts_f * (fa * F(w.M, w.D, w.dim_x) - outer))
+            kern['backward_pass_adjoint'] = (stash_ms['backward_pass_adjoint'] * 1e-3, pts_b * (fa * F(w.M, w.D, w.dim_out_b) - outer))
+            kern['stash_contraction'] = (stash_ms['stash_contraction'] * 1e-3, (pts_f + pts_b) * outer)
+            launches = dict(stash_n)
+        if mode == 'train' and not stash:
             cL, cE = float(cfg['loss_factors'][0]) / w.S, float(cfg['loss_factors'][1]) / w.S
 
             def k_rfwd():
@@ -309,17 +405,14 @@ def main():
                                                          ops._ptr(ws.h_all), ops._ptr(ws.fmv_b), ops._ptr(ws.a2s_b),
                                                          ops._ptr(ws.gy2), cE,
                                                          ops._ptr(ws.gpart_b), st), 'rev bwd')
-            # adjoint of one GP evaluation: the reverse sweep costs 2F (K^-1 A2bar and the A2bar K^T outer product);
-            # without the saved A2 tiles the kernel also recomputes the evaluation itself (+F)  
-            fa = 2.0 if ws.a2s_b is not None else 3.0
-            kern['forward_pass_adjoint'] = (time_kernel(k_rfwd, 5), fa * (w.T - 1) * N * F(w.M, w.D, w.dim_x))
-            kern['backward_pass_adjoint'] = (time_kernel(k_rbwd, 5), fa * 2.0 * w.T * N * F(w.M, w.D, w.dim_out_b))
+            kern['forward_pass_adjoint'] = (time_kernel(k_rfwd, 5), fa * pts_f * F(w.M, w.D, w.dim_x))
+            kern['backward_pass_adjoint'] = (time_kernel(k_rbwd, 5), fa * pts_b * F(w.M, w.D, w.dim_out_b))
         # The forward-direction kernels run one workgroup per 16-chain group: 320 groups on 256 CUs make the full launch
         # two rounds at 62.5 % occupancy.  The step does not run them that way (hip/train.py:_split: a main piece of whole
         # rounds, the remainder overlapped with the many-workgroup backward-run kernels on a second stream), so the
         # main-piece launch is timed too: what these kernels achieve as scheduled.
         main_piece = None
-        if mode == 'train' and not stepper.engine.stash:
+        if mode == 'train' and not stash:
             split = stepper.engine._split(prob)
             if split is not None:
                 groups = (N + 15) // 16
@@ -350,7 +443,7 @@ def main():
         # (profiles/tools/collect_traffic.sh) are committed per round; the newest file that has the entry is quoted and
         # named in `traffic_source`
         traffic, traffic_source = None, None
-        for rnd in ('r02', 'r01'):
+        for rnd in ('r03', 'r02', 'r01'):
             tpath = os.path.join(ROOT, 'profiles', rnd, 'traffic.json')
             if os.path.exists(tpath):
                 val = json.load(open(tpath)).get('%s:%s' % (args.workload, mode), {}).get(name)
@@ -363,6 +456,14 @@ def main():
                 'kernel_ms': {k: v[0] * 1e3 for k, v in kern.items()},
                 'kernel_tflops': {k: v[1] / v[0] / 1e12 for k, v in kern.items()},
                 'main_piece': main_piece,
+                'stash_mode': None if not stash else {
+                    'launches': launches, 'bookkeeping_ms': stash_ms.get('reductions'),
+                    'adjoint_with_contraction': {
+                        'ms': sum(stash_ms[k] for k in ('forward_pass_adjoint', 'backward_pass_adjoint', 'stash_contraction')),
+                        'tflops': fa * (pts_f * F(w.M, w.D, w.dim_x) + pts_b * F(w.M, w.D, w.dim_out_b)) / 1e9 /
+                        sum(stash_ms[k] for k in ('forward_pass_adjoint', 'backward_pass_adjoint', 'stash_contraction'))},
+                    'note': 'M > 112: each adjoint is a series of time-chunked launches (their times are summed); the A2bar K^T '
+                            'outer product runs in cbfssm_stash_contract_f64 and is priced there (2 M^2 flops per GP point)'},
                 'hbm_kernel': {'kernel': 'loglik_moments', 'bound': 'hbm', 'ms': t_ll * 1e3,
                                'achieved': ll_bytes / t_ll / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': ll_bytes / t_ll / 1e9 / HBM_PEAK_GBS},
@@ -383,10 +484,12 @@ def main():
                        'mode': mode, 'global_batch': w.B * world, 'seq_len': w.T, 'particles': w.S,
                        'parallelism': 'dp%d' % world},
             'loss': loss,
+            'collective': coll,
+            'params': args.params,
             'roofline': roof,
         }
         if not args.no_cpu_baseline and world == 1 and args.dtype == 'float64':
-            rec['cpu_baseline'] = cpu_baseline(w, mode, full=(args.cpu_baseline == 'full'))
+            rec['cpu_baseline'] = cpu_baseline(w, mode, policy=args.cpu_baseline)
             rec['speedup_vs_cpu_baseline'] = rec['value'] / rec['cpu_baseline']['value']
         else:
             rec['cpu_baseline'] = None

@@ -474,7 +474,10 @@ class HipElboGrad:
         sf, sb = self.slab_f, self.slab_b
         nseg = int(lib.cbfssm_bwd_segments(pb))
         per_b = max(1, cols_b // (groups * 2 * P * 16))
-        overlap = not os.environ.get('CBFSSM_NO_SPLIT')
+        # measurement hook (bench.py): with a list in self._prof every launch of this schedule is bracketed by HIP events on
+        # ONE stream (no overlap between the two directions), so that each kernel's own time can be summed per kind
+        prof = getattr(self, '_prof', None)
+        overlap = not os.environ.get('CBFSSM_NO_SPLIT') and prof is None
         s0 = torch.cuda.current_stream()
         s1 = self._side_stream() if overlap else s0
         st0, st1 = C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)
@@ -491,24 +494,34 @@ class HipElboGrad:
         if overlap:
             s1.wait_stream(s0)                               # the forward evaluation and the zeroing above
 
+        def timed(kind, stream, fn):
+            if prof is None:
+                return fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            prof.append((kind, e0, e1))
+
         def rfwd(t_hi, t_lo):
             """forward-pass adjoint of steps t_hi .. t_lo (descending) in launches that fit the stash, on s0"""
             per = max(1, cols_f // (groups * 16))
             while True:
                 lo = max(t_lo, t_hi - per + 1)
                 cols = groups * max(0, t_hi - lo + 1) * 16
-                rc = lib.cbfssm_forward_pass_bwd_ex_f64(pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
-                                                        _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2),
-                                                        e_eps, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2),
-                                                        _ptr(ws.gpart_f), t_hi, lo, _ptr(ws.gx_carry), _ptr(sa_f),
-                                                        _ptr(sk_f), cols, st0)
-                _l.check(rc, 'cbfssm_forward_pass_bwd_ex_f64')
+                timed('forward_pass_adjoint', s0, lambda: _l.check(lib.cbfssm_forward_pass_bwd_ex_f64(
+                    pb, C.byref(self.pack_f.layout), _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y),
+                    _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), t_hi, lo,
+                    _ptr(ws.gx_carry), _ptr(sa_f), _ptr(sk_f), cols, st0), 'cbfssm_forward_pass_bwd_ex_f64'))
                 ev = torch.cuda.Event()
                 ev.record(s0)                                # gy2[t] is final for every t > lo (and t = 0 once lo = 0)
-                _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp_f[:sf]), st0), 'reduce f')
-                red[:sf] += tmp_f[:sf]
+
+                def red_f():
+                    _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp_f[:sf]), st0), 'reduce f')
+                    red[:sf] += tmp_f[:sf]
+                timed('reductions', s0, red_f)
                 if cols:
-                    con_f.add(sa_f, sk_f, cols, st0)
+                    timed('stash_contraction', s0, lambda: con_f.add(sa_f, sk_f, cols, st0))
                 if lo <= t_lo or t_hi < 0:
                     return ev
                 t_hi = lo - 1
@@ -517,14 +530,16 @@ class HipElboGrad:
             """both backward runs, segments [seg0, seg1), on s1"""
             cols = groups * 2 * (seg1 - seg0) * P * 16
             with torch.cuda.stream(s1):
-                rc = lib.cbfssm_backward_pass_bwd_ex_f64(pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf),
-                                                         _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
-                                                         _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.gy2), cE,
-                                                         _ptr(ws.gpart_b), seg0, seg1, 1, _ptr(sa_b), _ptr(sk_b), cols, st1)
-                _l.check(rc, 'cbfssm_backward_pass_bwd_ex_f64')
-                _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, 2 * groups, _ptr(tmp_b[:sb]), st1), 'reduce b')
-                red[sf:sf + sb] += tmp_b[:sb]
-                con_b.add(sa_b, sk_b, cols, st1)
+                timed('backward_pass_adjoint', s1, lambda: _l.check(lib.cbfssm_backward_pass_bwd_ex_f64(
+                    pb, C.byref(self.pack_b.layout), _ptr(self.pack_b.buf), _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b),
+                    _ptr(eps_b), _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), seg0, seg1, 1,
+                    _ptr(sa_b), _ptr(sk_b), cols, st1), 'cbfssm_backward_pass_bwd_ex_f64'))
+
+                def red_b():
+                    _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, 2 * groups, _ptr(tmp_b[:sb]), st1), 'reduce b')
+                    red[sf:sf + sb] += tmp_b[:sb]
+                timed('reductions', s1, red_b)
+                timed('stash_contraction', s1, lambda: con_b.add(sa_b, sk_b, cols, st1))
 
         t_hi = T - 2                                         # next forward-pass-adjoint step to process
         seg1 = nseg
@@ -764,7 +779,7 @@ class HipTrainStep:
                 torch.cuda.synchronize(dev)
                 self.opt._t = t_before
                 self.use_graph = False
-                return self.step(u, y, noise, condition)
+                return self.step(u, y, noise, condition, weight=weight)
             g.update(graph=graph, front=front, state=state, loss=loss, terms=terms, ws=state['ws'])
             self._graphs[key] = g
         else:
