@@ -25,6 +25,7 @@ SYMBOLS = (
     'cbfssm_train_tail_f64', 'cbfssm_adam_step_f64', 'cbfssm_loglik_partials', 'cbfssm_data_tail_f64', 'cbfssm_stash_contract_work_elems', 'cbfssm_stash_contract_f64',
     'cbfssm_cholesky_f64', 'cbfssm_rbf_k_f64', 'cbfssm_gp_predict_fullq_work_elems', 'cbfssm_gp_predict_fullq_f64',
     'cbfssm_pack_f32_elems', 'cbfssm_gp_pack_f32', 'cbfssm_gp_pack_bf16', 'cbfssm_gp_predict_f32', 'cbfssm_backward_pass_f32', 'cbfssm_forward_pass_f32',
+    'cbfssm_rev32_slab_elems', 'cbfssm_forward_pass_bwd_f32', 'cbfssm_backward_pass_bwd_f32',
 )
 
 
@@ -116,10 +117,16 @@ def load():
     lib.cbfssm_gp_pack_f32.argtypes = [C.POINTER(PackLayout), vp, vp, vp]
     lib.cbfssm_gp_pack_bf16.argtypes = [C.POINTER(PackLayout), vp, vp, vp]
     lib.cbfssm_gp_predict_f32.argtypes = [C.POINTER(PackLayout), vp, vp, i64, vp, vp, vp]
-    lib.cbfssm_backward_pass_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9
-    lib.cbfssm_forward_pass_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 10
+    lib.cbfssm_backward_pass_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 11
+    lib.cbfssm_forward_pass_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 11
+    lib.cbfssm_rev32_slab_elems.restype = i64
+    lib.cbfssm_rev32_slab_elems.argtypes = [C.POINTER(PackLayout)]
+    lib.cbfssm_forward_pass_bwd_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, vp, vp]
+    lib.cbfssm_backward_pass_bwd_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
+        if name == 'cbfssm_rev32_slab_elems':
+            continue
         if fn.restype is C.c_int or name.endswith('_f64') or name.endswith('_f32') or name.endswith('_bf16') or name in ('cbfssm_gp_pack_layout', 'cbfssm_bwd_segments',
                                                                         'cbfssm_param_layout_init'):
             fn.restype = ip

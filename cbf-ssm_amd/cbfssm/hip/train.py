@@ -89,15 +89,16 @@ class HipElboGrad:
         self.config = config
         self.device = torch.device(device)
         self.dist = dist
-        # float32: the time loops of the FORWARD evaluation compute in float32 (cbfssm_*_pass_f32); there is no float32
-        # adjoint, so a float32 engine serves loss / prediction fetches only
+        # float32: the time loops of the forward evaluation AND of the adjoint compute in float32 (cbfssm_*_pass_f32,
+        # cbfssm_*_pass_bwd_f32); K_mm / Cholesky / K^-1, their adjoint and the optimizer step stay float64, as the
+        # reference's float32 models keep the Cholesky in float64 (gp_tf.py:57-65)
         assert dtype in ('float64', 'float32')
         self.f32 = dtype == 'float32'
         self.dim_u, self.dim_y, self.dim_x = config['ds'].dim_u, config['ds'].dim_y, config['dim_x']
         self.M, self.S = config['ind_pnt_num'], config['samples']
         self.D = self.dim_x + self.dim_u
         self.dob = self.dim_x - self.dim_y
-        mode = ops.gp_form_mode(config) if not self.f32 else 'dense'
+        mode = ops.gp_form_mode(config) if not self.f32 else ops.gp_form_mode_f32(config)
         self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device, mode)
         self.pack_b = GPPack(self.M, self.D, self.dob, self.device, mode)
         self.has_adjoint = all(pk.layout.rev_slab > 0 for pk in (self.pack_f, self.pack_b))
@@ -109,6 +110,10 @@ class HipElboGrad:
             self._need_adjoint()
         self.slab_f = max(0, int(self.pack_f.layout.rev_slab))
         self.slab_b = max(0, int(self.pack_b.layout.rev_slab))
+        if self.f32:
+            # per-workgroup slabs of the float32 adjoint: the non-stash layout at every tile height (Kinvbar included)
+            self.slab32_f = int(_l.load().cbfssm_rev32_slab_elems(C.byref(self.pack_f.layout)))
+            self.slab32_b = int(_l.load().cbfssm_rev32_slab_elems(C.byref(self.pack_b.layout)))
         self.last_ws = None
         # flat reduce buffer: [slab_f | slab_b | loglik, kl_x, entropy, gvy_ll[dim_y] | stash mode: the two contracted
         # d loss / d K^-1 images] -- everything a data-parallel step exchanges, in ONE all-reduce
@@ -135,9 +140,6 @@ class HipElboGrad:
         return tuple(pk.update_form() for pk in (self.pack_f, self.pack_b))
 
     def _need_adjoint(self):
-        if self.f32:
-            raise NotImplementedError('float32 models evaluate the ELBO and the predictions; the gradient path (model.train) '
-                                      'computes in float64 only')
         if not self.has_adjoint:
             raise _l.CbfssmHipError('no adjoint kernel for M=%d (tile height %d)' % (self.M, self.pack_f.layout.NBLK))
 
@@ -211,12 +213,20 @@ class HipElboGrad:
     def _workspace(self, prob):
         key = (prob.B, prob.T)
         if key not in self._ws:
-            ws = ops.ElboWorkspace(prob, self.device, keep_h=True, packs=(self.pack_f, self.pack_b), pool=self.tile_pool)
+            # (the float32 adjoint recomputes the kernel tile and A2: no saved tiles)
+            ws = ops.ElboWorkspace(prob, self.device, keep_h=True, packs=None if self.f32 else (self.pack_f, self.pack_b),
+                                   pool=self.tile_pool)
             lib = _l.load()
             n_f = int(lib.cbfssm_rev_workgroups(C.byref(prob), 0))
             n_b = int(lib.cbfssm_rev_workgroups(C.byref(prob), 1))
             f = dict(dtype=torch.float64, device=self.device)
             ws.gy2 = torch.zeros_like(ws.y2)
+            if self.f32:
+                ws.gpart_f = torch.zeros((n_f + 32) * self.slab32_f, **f)
+                ws.gpart_b = torch.zeros((n_b + 32) * self.slab32_b, **f)
+                ws.n_f, ws.n_b = n_f, n_b
+                self._ws[key] = ws
+                return ws
             if self.stash:
                 n_b = 2 * n_f          # one launch per segment range, grid.z = 1
                 ws.gx_carry = torch.zeros(prob.B * prob.S, prob.dim_x, **f)
@@ -270,8 +280,10 @@ class HipElboGrad:
         red = self.red
         sf, sb = self.slab_f, self.slab_b
         gB_f = gB_b = None
-        split = self._split(prob)
-        if not self.stash and split is not None:
+        split = self._split(prob) if not self.f32 else None
+        if self.f32:
+            gB_f, gB_b = self._adjoint_f32(prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red)
+        elif not self.stash and split is not None:
             self._adjoint_split(prob, split, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE)
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
@@ -446,6 +458,45 @@ class HipElboGrad:
         e3.record(s1)
         rbwd(p_rest, st0)
         s0.wait_event(e3)
+
+    def _adjoint_f32(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):
+        """float32 adjoint (cbfssm_*_pass_bwd_f32): one call per direction (above 208 inducing points a call is two passes
+        over the time loop), float64 slabs in the non-stash layout reduced by the float64 reduction.  For the tile heights
+        whose float64 adjoint runs in stash mode the Kinvbar section of the reduced slab is handed to the train tail the
+        way the stash contraction's images are."""
+        lib = _l.load()
+        pb = C.byref(prob)
+        st = _stream()
+        b32f, b32b = self.pack_f.buf32, self.pack_b.buf32           # filled by the forward evaluation (ops.elbo_forward)
+        sf, sb = self.slab_f, self.slab_b
+        e_eps = _ptr(eps_f) if eps_f.numel() else None
+        _l.check(lib.cbfssm_forward_pass_bwd_f32(pb, C.byref(self.pack_f.layout), C.c_void_p(b32f.data_ptr()), _ptr(c['var_x']),
+                                                 _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f),
+                                                 cL, _ptr(ws.gy2), _ptr(ws.gpart_f), st), 'cbfssm_forward_pass_bwd_f32')
+        _l.check(lib.cbfssm_backward_pass_bwd_f32(pb, C.byref(self.pack_b.layout), C.c_void_p(b32b.data_ptr()), _ptr(c['var_x']),
+                                                  _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b), _ptr(ws.h_all), _ptr(ws.fmv_b),
+                                                  _ptr(ws.gy2), cE, _ptr(ws.gpart_b), st), 'cbfssm_backward_pass_bwd_f32')
+        if not self.stash:
+            assert self.slab32_f == sf and self.slab32_b == sb
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
+            return None, None
+        if getattr(self, '_tmp32', None) is None:
+            self._tmp32 = torch.zeros(self.slab32_f + self.slab32_b, dtype=torch.float64, device=self.device)
+        tf, tb = self._tmp32[:self.slab32_f], self._tmp32[self.slab32_f:]
+        _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), self.slab32_f, ws.n_f, _ptr(tf), st), 'reduce f')
+        _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), self.slab32_b, ws.n_b, _ptr(tb), st), 'reduce b')
+        o = self.nred
+        imgs = []
+        for t32, lo, n, nimg, io in ((tf, 0, sf, self.nimg_f, o), (tb, sf, sb, self.nimg_b, o + self.nimg_f)):
+            nb = int(round((nimg // 256) ** 0.5))
+            og = 2 * nb * 256                                        # [mubar | s2bar] precede the Kinvbar images
+            red[lo:lo + og].copy_(t32[:og])
+            red[lo + og:lo + n].copy_(t32[og + nimg:])
+            img = red[io:io + nimg]
+            img.copy_(t32[og:og + nimg])
+            imgs.append(img)
+        return imgs[0], imgs[1]
 
     def _adjoint_stash(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):
         """Stash-mode adjoint (M > 112): time-chunked launches, every launch followed by one float64 GEMM that
@@ -699,11 +750,11 @@ class TFAdam:
 class HipTrainStep:
     """One `sess.run((model.train, model.loss))` (training/trainer.py:40): loss, gradient, Adam update."""
 
-    def __init__(self, config, params, device, dist=None, graph=None, engine=None, opt=None):
+    def __init__(self, config, params, device, dist=None, graph=None, engine=None, opt=None, dtype='float64'):
         """Either builds its own engine and optimiser from (config, params), or drives the pair a model object already
         owns (`engine`, `opt`: cbfssm.model.CBFSSM)."""
         if engine is None:
-            engine = HipElboGrad(config, device, dist)
+            engine = HipElboGrad(config, device, dist, dtype=dtype)
             opt = TFAdam({k: _f64(params[k], device).clone() for k in PARAM_NAMES}, config['learning_rate'])
         self.engine, self.opt = engine, opt
         self.params = self.opt.views

@@ -11,89 +11,52 @@
 // (row = (lane >> 4) + 4 reg), so the "accumulator is the next product's B operand" chain of the f64 kernels holds here
 // with a PERMUTED k order: register r of row block b is the B operand of a k-step whose four k indices are the rows
 // 16 b + r, + 4, + 8, + 12.  The float32 operand images are packed in that order (pack32_kernel).
-#include <hip/hip_runtime.h>
-#include <cstring>
-#include "../../include/cbfssm_hip.h"
-#include "cbfssm_kernels.hpp"
+#include "cbfssm_f32.hpp"
 
 namespace cbfssm {
-
-int fail(int code, const char* fmt, ...);
-
 namespace f32 {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-#define CBF_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-// float -> the nearest bfloat16 value (round to nearest even on the dropped 16 mantissa bits), kept in a float: the
-// bf16-operand mode of the sweep rounds the two operands of the K^-1 K contraction this way and multiplies them on the
-// float32 MFMA -- products of bf16 values are exact in float32, so this is the arithmetic of a bf16-operand /
-// float32-accumulate MFMA up to the order of the accumulation (it measures the precision, it is not a throughput path).
-__host__ __device__ __forceinline__ float round_bf16(float x)
-{
-    union { float f; uint32_t u; } v;
-    v.f = x;
-    v.u = (v.u + 0x7FFFu + ((v.u >> 16) & 1u)) & 0xFFFF0000u;
-    return v.f;
-}
-
-struct Pack32 {
-    const float* Bp;     // [NBLK][KS][64]  K^-1, A-operand image, permuted k order
-    const float* Zp;     // [NBLK][DK][64]  Z / lengthscale, A-operand image (natural k order: the inputs' dimensions)
-    const float* cz;     // [Mp]
-    const float* mu;     // [NBLK][4][64]   zeta_mean, A-operand image, permuted k order
-    const float* s2;     // [NBLK][4][64]   zeta_var
-    const float* invl;   // [Dp]
-    const float* scal;   // [0] = sigma^2, [1] = 1 when the contraction operands are rounded to bf16
-};
-
-struct Off32 {
-    int64_t Bp, Zp, cz, mu, s2, invl, scal, total;
-};
-
-static Off32 pack32_offsets(const cbfssm_pack_layout* L)
-{
-    Off32 o;
-    int64_t p = 0;
-    auto take = [&](int64_t n) { int64_t r = p; p += (n + 63) / 64 * 64; return r; };
-    o.Bp = take(int64_t(L->NBLK) * L->KS * 64);
-    o.Zp = take(int64_t(L->NBLK) * L->DK * 64);
-    o.cz = take(L->Mp);
-    o.mu = take(int64_t(L->NBLK) * 256);
-    o.s2 = take(int64_t(L->NBLK) * 256);
-    o.invl = take(L->Dp);
-    o.scal = take(64);
-    o.total = p;
-    return o;
-}
-
-__global__ void pack32_kernel(const double* pack, int64_t oBp, int64_t oZp, int64_t ocz, int64_t omu, int64_t os2,
-                              int64_t oinvl, int64_t oscal, float* out, Off32 o, int NBLK, int KS, int DK, int Mp, int Dp,
-                              int bf16)
+__global__ void pack32_kernel(const double* pack, cbfssm_pack_layout L, float* out, Off32 o, int bf16)
 {
     const int64_t tid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x, nt = int64_t(gridDim.x) * blockDim.x;
-    // K^-1: target (rb, s, g, nl) holds Kinv[16 rb + nl][16 (s >> 2) + 4 g + (s & 3)]; the f64 image holds
-    // Kinv[16 rb + nl][4 s' + g'] at (rb, s', g', nl)  ->  s' = 4 (s >> 2) + g, g' = s & 3
+    const int NBLK = L.NBLK, KS = L.KS, DK = L.DK, Mp = L.Mp, Dp = L.Dp, JB = L.JB;
+    // K^-1 (and W = L^-1, W^T for the two-triangular form): target (rb, s, g, nl) holds Kinv[16 rb + nl][16 (s >> 2) + 4 g +
+    // (s & 3)]; the f64 image holds Kinv[16 rb + nl][4 s' + g'] at (rb, s', g', nl)  ->  s' = 4 (s >> 2) + g, g' = s & 3
     for (int64_t i = tid; i < int64_t(NBLK) * KS * 64; i += nt) {
         const int l = int(i & 63), s = int((i >> 6) % KS), rb = int((i >> 6) / KS);
         const int g = l >> 4, nl = l & 15;
         const int sp = 4 * (s >> 2) + g, gp = s & 3;
-        const float kv = float(pack[oBp + (int64_t(rb) * KS + sp) * 64 + gp * 16 + nl]);
+        const int64_t src = (int64_t(rb) * KS + sp) * 64 + gp * 16 + nl;
+        const float kv = float(pack[L.Bp + src]);
         out[o.Bp + i] = bf16 ? round_bf16(kv) : kv;
+        out[o.Wp + i] = float(pack[L.Wp + src]);
+        out[o.WTp + i] = float(pack[L.WTp + src]);
+        out[o.BpN + i] = float(pack[L.Bp + i]);                 // natural k order (adjoint: B operands from LDS tiles)
+        out[o.WpN + i] = float(pack[L.Wp + i]);
+        out[o.WTpN + i] = float(pack[L.WTp + i]);
     }
-    for (int64_t i = tid; i < int64_t(NBLK) * DK * 64; i += nt) out[o.Zp + i] = float(pack[oZp + i]);
-    for (int64_t i = tid; i < Mp; i += nt) out[o.cz + i] = float(pack[ocz + i]);
+    for (int64_t i = tid; i < int64_t(NBLK) * DK * 64; i += nt) out[o.Zp + i] = float(pack[L.Zp + i]);
+    for (int64_t i = tid; i < Mp; i += nt) out[o.cz + i] = float(pack[L.cz + i]);
     // zeta_mean / zeta_var: target (rb, r, g, nl) holds z[16 rb + 4 g + r][nl]; the f64 image holds z[16 rb + 4 r' + g'][nl]
     for (int64_t i = tid; i < int64_t(NBLK) * 256; i += nt) {
         const int l = int(i & 63), r = int((i >> 6) & 3), rb = int(i >> 8);
         const int g = l >> 4, nl = l & 15;
         const int64_t src = (int64_t(rb) * 4 + g) * 64 + r * 16 + nl;
-        out[o.mu + i] = float(pack[omu + src]);
-        out[o.s2 + i] = float(pack[os2 + src]);
+        out[o.mu + i] = float(pack[L.muA + src]);
+        out[o.s2 + i] = float(pack[L.s2A + src]);
+        out[o.muB + i] = float(pack[L.muB + i]);
+        out[o.s2B + i] = float(pack[L.s2B + i]);
     }
-    for (int64_t i = tid; i < Dp; i += nt) out[o.invl + i] = float(pack[oinvl + i]);
+    // (Z~)^T: target ((rb, jb), r, g, nl) holds ZT[j = 16 jb + nl][m = 16 rb + 4 g + r]; the f64 image holds m = 16 rb + 4 s' + g'
+    for (int64_t i = tid; i < int64_t(NBLK) * JB * 256; i += nt) {
+        const int l = int(i & 63), r = int((i >> 6) & 3);
+        const int64_t blk = i >> 8;
+        const int g = l >> 4, nl = l & 15;
+        out[o.ZTq + i] = float(pack[L.ZT + (blk * 4 + g) * 64 + r * 16 + nl]);
+    }
+    for (int64_t i = tid; i < Dp; i += nt) out[o.invl + i] = float(pack[L.invl + i]);
     if (tid == 0) {
-        out[o.scal] = float(pack[oscal + CBFSSM_SCAL_SIGMA2]);
+        out[o.scal] = float(pack[L.scal + CBFSSM_SCAL_SIGMA2]);
         out[o.scal + 1] = bf16 ? 1.0f : 0.0f;
     }
 }
@@ -115,6 +78,9 @@ struct Args32 {
     double* y2_out;
     double* x_out;
     double* part_out;
+    double* fmv;          // optional: (fmean, fvar) of every step, kept for the adjoint (PassArgs::fmv layout)
+    double* h_all;        // optional (backward runs): every step's output of both runs
+    int tri;              // 1: two-triangular GP form (layout->gp_form == CBFSSM_GP_FORM_TRI)
     int nseg0;
     // predict
     const double* X;
@@ -123,17 +89,6 @@ struct Args32 {
     double* fvar;
 };
 
-__device__ __forceinline__ float rcp32(float x)
-{
-    float r = __builtin_amdgcn_rcpf(x);
-    return fmaf(r, fmaf(-x, r, 1.0f), r);
-}
-__device__ __forceinline__ float rsqrt32(float x)
-{
-    float y = __builtin_amdgcn_rsqf(x);
-    return fmaf(y, fmaf(-0.5f * x * y, y, 0.5f), y);
-}
-
 template <int NBLK, int RB, int DK>
 struct Tile32 {
     static constexpr int W = (NBLK + RB - 1) / RB;
@@ -141,11 +96,13 @@ struct Tile32 {
     static constexpr int MP = 16 * NBLK;
     static constexpr int KS = MP / 4;
     static constexpr int QPW = (4 + W - 1) / W;
-    static constexpr int LDS_FLOATS = DK * 64 + MP * 16 + W * 512;
+    static constexpr int LDS_FLOATS = DK * 64 + 2 * MP * 16 + W * 512;     // xq, K tile, A tile (two-triangular form), partials
 
     float Zreg[RB][DK];
     float czr[RB][4];
     const float* Bp;
+    const float* Wp;
+    const float* WTp;
     const float* mu;
     const float* s2;
     float sigma2;
@@ -153,7 +110,7 @@ struct Tile32 {
 
     __device__ __forceinline__ void load(const Pack32& pk, int w, int l)
     {
-        Bp = pk.Bp; mu = pk.mu; s2 = pk.s2; sigma2 = pk.scal[0];
+        Bp = pk.Bp; Wp = pk.Wp; WTp = pk.WTp; mu = pk.mu; s2 = pk.s2; sigma2 = pk.scal[0];
         bf16 = pk.scal[1] != 0.0f;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -167,8 +124,14 @@ struct Tile32 {
         }
     }
 
-    // kernel tile (gp_tf.py:33-49,134) -> LDS, then A2 = K^-1 K and the predictive products (gp_tf.py:137-159)
-    __device__ __forceinline__ void gp(const float* xq, float* Kt, float* part, int w, int l)
+    // kernel tile (gp_tf.py:33-49,134) -> LDS, then A2 = K^-1 K and the predictive products (gp_tf.py:137-159).
+    // TRI: the reference's own order (gp_tf.py:137-145) as two triangular products that skip the zero blocks --
+    // A = W K with W = L^-1 (row block rb needs the k-blocks 0..rb), fvar_0 = sigma^2 - colsum(A o A), A2 = W^T A (k-blocks
+    // rb..NBLK-1; the rows of A travel through a second LDS tile, one more workgroup barrier).  In float32 this is the form
+    // that keeps fvar_0 meaningful on an ill-conditioned K_mm: a sum of squares instead of sigma^2 - k.(K^-1 k), whose two
+    // terms agree to cond eps_32.
+    template <bool TRI>
+    __device__ __forceinline__ void gp(const float* xq, float* Kt, float* At, float* part, int w, int l)
     {
         float bx[DK], xx = 0.0f;
 #pragma unroll
@@ -191,7 +154,7 @@ struct Tile32 {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     kreg[i][r] = expf(e[r]);
-                    if (bf16) kreg[i][r] = round_bf16(kreg[i][r]);  // (the kernel tile is the contraction's other operand)
+                    if (!TRI && bf16) kreg[i][r] = round_bf16(kreg[i][r]);  // (the kernel tile is the contraction's other operand)
                     Kt[(4 * rb + r) * 64 + l] = kreg[i][r];         // B operand of the (permuted) k-step 4 rb + r
                 }
             } else {
@@ -203,23 +166,73 @@ struct Tile32 {
         f4 acc[RB][2];
 #pragma unroll
         for (int i = 0; i < RB; ++i) { acc[i][0] = f4{0, 0, 0, 0}; acc[i][1] = f4{0, 0, 0, 0}; }
+        float q = 0.0f;
+        if constexpr (!TRI) {
 #pragma unroll 1
-        for (int s0 = 0; s0 < KS; s0 += 4) {
-            float b[4], aop[RB][4];
+            for (int s0 = 0; s0 < KS; s0 += 4) {
+                float b[4], aop[RB][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                b[j] = Kt[64 * (s0 + j) + l];
+                for (int j = 0; j < 4; ++j) {
+                    b[j] = Kt[64 * (s0 + j) + l];
 #pragma unroll
-                for (int i = 0; i < RB; ++i) aop[i][j] = Bp[(min(w * RB + i, NBLK - 1) * KS + s0 + j) * 64 + l];
+                    for (int i = 0; i < RB; ++i) aop[i][j] = Bp[(min(w * RB + i, NBLK - 1) * KS + s0 + j) * 64 + l];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+                        if (w * RB + i < NBLK) acc[i][j & 1] = CBF_MFMA32(aop[i][j], b[j], acc[i][j & 1]);
+            }
+        } else {
+            // A = W K: k-block kb contributes to row block rb when kb <= rb (W is lower triangular)
+#pragma unroll 1
+            for (int kb = 0; kb < NBLK; ++kb) {
+                if (kb > min(w * RB + RB - 1, NBLK - 1)) break;
+                float b[4], aop[RB][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    b[j] = Kt[64 * (4 * kb + j) + l];
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) aop[i][j] = Wp[(min(w * RB + i, NBLK - 1) * KS + 4 * kb + j) * 64 + l];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+                        if (w * RB + i < NBLK && kb <= w * RB + i) acc[i][j & 1] = CBF_MFMA32(aop[i][j], b[j], acc[i][j & 1]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < RB; ++i) {
+                const int rb = w * RB + i;
+                if (rb < NBLK) {
+                    const f4 av = acc[i][0] + acc[i][1];
 #pragma unroll
-                for (int i = 0; i < RB; ++i)
-                    if (w * RB + i < NBLK) acc[i][j & 1] = CBF_MFMA32(aop[i][j], b[j], acc[i][j & 1]);
+                    for (int r = 0; r < 4; ++r) {
+                        q = fmaf(av[r], av[r], q);                  // colsum(A o A), this wave's rows   (gp_tf.py:140)
+                        At[(4 * rb + r) * 64 + l] = av[r];
+                    }
+                }
+                acc[i][0] = f4{0, 0, 0, 0}; acc[i][1] = f4{0, 0, 0, 0};
+            }
+            __syncthreads();
+            // A2 = W^T A: k-blocks kb >= rb
+#pragma unroll 1
+            for (int kb = w * RB; kb < NBLK; ++kb) {
+                float b[4], aop[RB][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    b[j] = At[64 * (4 * kb + j) + l];
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) aop[i][j] = WTp[(min(w * RB + i, NBLK - 1) * KS + 4 * kb + j) * 64 + l];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+                        if (w * RB + i < NBLK && kb >= w * RB + i) acc[i][j & 1] = CBF_MFMA32(aop[i][j], b[j], acc[i][j & 1]);
+            }
         }
         f4 P1 = {0, 0, 0, 0}, P2 = {0, 0, 0, 0};
-        float q = 0.0f;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int rb = w * RB + i;
@@ -229,7 +242,7 @@ struct Tile32 {
                 for (int r = 0; r < 4; ++r) {
                     P1 = CBF_MFMA32(mu[(rb * 4 + r) * 64 + l], a2[r], P1);
                     P2 = CBF_MFMA32(s2[(rb * 4 + r) * 64 + l], a2[r] * a2[r], P2);
-                    q = fmaf(kreg[i][r], a2[r], q);
+                    if constexpr (!TRI) q = fmaf(kreg[i][r], a2[r], q);
                 }
             }
         }
@@ -256,14 +269,15 @@ struct Tile32 {
     }
 };
 
-template <int NBLK, int RB, int DK>
+template <int NBLK, int RB, int DK, bool TRI>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict32_kernel(Args32 a)
 {
     typedef Tile32<NBLK, RB, DK> TT;
     extern __shared__ float lds32[];
     float* xq = lds32;
     float* Kt = xq + DK * 64;
-    float* part = Kt + TT::MP * 16;
+    float* At = Kt + TT::MP * 16;
+    float* part = At + TT::MP * 16;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
     TT tile;
     tile.load(a.pk, w, l);
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict32_kernel(
         xq[i] = v;
     }
     __syncthreads();
-    tile.gp(xq, Kt, part, w, l);
+    tile.template gp<TRI>(xq, Kt, At, part, w, l);
     __syncthreads();
 #pragma unroll
     for (int qi = 0; qi < TT::QPW; ++qi) {
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void predict32_kernel(
 // Persistent pass kernel in float32 arithmetic: MODE_FWD = CBFSSM._forward_body loop (cbfssm.py:176-237), MODE_BWD = one
 // resample-to-resample segment of one _backward_body run (cbfssm.py:107-158).  Same structure as pass_kernel
 // (cbfssm_kernels.hpp): one workgroup = 16 chains, T looped inside, three workgroup barriers per step.
-template <int NBLK, int RB, int DK, int MODE>
+template <int NBLK, int RB, int DK, int MODE, bool TRI>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Args32 a)
 {
     typedef Tile32<NBLK, RB, DK> TT;
@@ -307,7 +321,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
     __shared__ double red[16];
     float* xq = lds32;
     float* Kt = xq + DK * 64;
-    float* part = Kt + TT::MP * 16;
+    float* At = Kt + TT::MP * 16;
+    float* part = At + TT::MP * 16;
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do;
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) auxr[k2] = has_next ? aux_load(k2, tn) : 0.0;
 
-        tile.gp(xq, Kt, part, w, l);                      // (one workgroup barrier inside)
+        tile.template gp<TRI>(xq, Kt, At, part, w, l);    // (one workgroup barrier inside, two in the two-triangular form)
         __syncthreads();                                  // part complete; xq and Kt free
 
 #pragma unroll
@@ -451,6 +466,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
                 if (act[qi]) {
                     const float fmean = fm + hcur[qi];                                     // cbfssm.py:145,205
                     const float fvar = fv + vx[qi];                                        // cbfssm.py:146,206
+                    if (a.fmv && cval) {
+                        const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                        double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
+                        o[0] = double(fmean); o[1] = double(fvar);
+                    }
                     if (MODE == MODE_FWD) {
                         const float vyt = vy[qi] + (a.k_factor - 1.0f) * fvar;             // cbfssm.py:212-214
                         const float sm = vyt + fvar;
@@ -474,6 +494,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
                             lp[qi].mul(double(fvar));                                      // :154-156
                             lin[qi] += 1.0;
                         }
+                        if (cval && a.h_all) a.h_all[((int64_t(run) * T + t) * N + c) * Do + d] = double(outv);
                     }
                 }
                 const float hn = (MODE == MODE_BWD && resample_n) ? hidn : outv;           // cbfssm.py:133-136,158
@@ -502,7 +523,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
     if (tid == 0) a.part_out[blockIdx.y * G16 + gx] = tot;
 }
 
-template <int NBLK, int DK>
+template <int NBLK, int DK, bool TRI>
 static int launch32(int mode, const Args32& a, dim3 grid, hipStream_t st)
 {
     constexpr int RB = (NBLK >= 13) ? 2 : 1;
@@ -513,17 +534,17 @@ static int launch32(int mode, const Args32& a, dim3 grid, hipStream_t st)
         if (lds > 48 * 1024) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     };
     if (mode == 2) {
-        auto k = predict32_kernel<NBLK, RB, DK>;
+        auto k = predict32_kernel<NBLK, RB, DK, TRI>;
         setlds(reinterpret_cast<const void*>(k));
         if (e != hipSuccess) return -int(e) - 1000;
         hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
     } else if (mode == MODE_FWD) {
-        auto k = pass32_kernel<NBLK, RB, DK, MODE_FWD>;
+        auto k = pass32_kernel<NBLK, RB, DK, MODE_FWD, TRI>;
         setlds(reinterpret_cast<const void*>(k));
         if (e != hipSuccess) return -int(e) - 1000;
         hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
     } else {
-        auto k = pass32_kernel<NBLK, RB, DK, MODE_BWD>;
+        auto k = pass32_kernel<NBLK, RB, DK, MODE_BWD, TRI>;
         setlds(reinterpret_cast<const void*>(k));
         if (e != hipSuccess) return -int(e) - 1000;
         hipLaunchKernelGGL(k, grid, dim3(TT::NT), lds, st, a);
@@ -535,10 +556,18 @@ static int launch32(int mode, const Args32& a, dim3 grid, hipStream_t st)
 template <int NBLK>
 static int launch32_n(int DK, int mode, const Args32& a, dim3 grid, hipStream_t st)
 {
+    if (a.tri) {
+        switch (DK) {
+            case 2: return launch32<NBLK, 2, true>(mode, a, grid, st);
+            case 4: return launch32<NBLK, 4, true>(mode, a, grid, st);
+            case 6: return launch32<NBLK, 6, true>(mode, a, grid, st);
+        }
+        return -2;
+    }
     switch (DK) {
-        case 2: return launch32<NBLK, 2>(mode, a, grid, st);
-        case 4: return launch32<NBLK, 4>(mode, a, grid, st);
-        case 6: return launch32<NBLK, 6>(mode, a, grid, st);
+        case 2: return launch32<NBLK, 2, false>(mode, a, grid, st);
+        case 4: return launch32<NBLK, 4, false>(mode, a, grid, st);
+        case 6: return launch32<NBLK, 6, false>(mode, a, grid, st);
     }
     return -2;
 }
@@ -558,15 +587,6 @@ static int dispatch32(int NBLK, int DK, int mode, const Args32& a, dim3 grid, hi
     return -2;
 }
 
-static Pack32 pack32_ptrs(const cbfssm_pack_layout* L, const float* p)
-{
-    const Off32 o = pack32_offsets(L);
-    Pack32 k;
-    k.Bp = p + o.Bp; k.Zp = p + o.Zp; k.cz = p + o.cz; k.mu = p + o.mu; k.s2 = p + o.s2; k.invl = p + o.invl;
-    k.scal = p + o.scal;
-    return k;
-}
-
 static int fill32(Args32& a, const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32, int Do)
 {
     if (!p || !L || !pack32) return fail(-1, "null pointer");
@@ -579,6 +599,7 @@ static int fill32(Args32& a, const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.N = p->B * p->S; a.S = p->S; a.T = p->T; a.B = p->B;
     a.dim_x = p->dim_x; a.dim_u = p->dim_u; a.dim_y = p->dim_y; a.Do = Do; a.D = L->D;
     a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = float(p->k_factor);
+    a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
     return 0;
 }
 
@@ -600,8 +621,7 @@ static int pack32_launch(const cbfssm_pack_layout* L, const double* pack, float*
 {
     if (!L || !pack || !pack32) return fail(-1, "null pointer");
     const Off32 o = pack32_offsets(L);
-    hipLaunchKernelGGL(pack32_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, pack, L->Bp, L->Zp, L->cz, L->muA, L->s2A,
-                       L->invl, L->scal, pack32, o, L->NBLK, L->KS, L->DK, L->Mp, L->Dp, bf16);
+    hipLaunchKernelGGL(pack32_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, pack, *L, pack32, o, bf16);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-int(e) - 1000, "gp_pack_f32: %s", hipGetErrorString(e));
 }
@@ -625,19 +645,21 @@ int cbfssm_gp_predict_f32(const cbfssm_pack_layout* L, const float* pack32, cons
     memset(&a, 0, sizeof(a));
     a.pk = pack32_ptrs(L, pack32);
     a.X = X; a.npts = npts; a.D = L->D; a.Do = L->Do; a.fmean = fmean; a.fvar = fvar;
+    a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
     int rc = dispatch32(L->NBLK, L->DK, 2, a, dim3(unsigned((npts + 15) / 16)), (hipStream_t)stream);
     return rc ? fail(rc, "gp_predict_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;
 }
 
 int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_b,
                              const double* var_x, const double* u, const double* y, const double* hid_b,
-                             const double* eps_b, double* y2, double* ent_part, void* stream)
+                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* ent_part, void* stream)
 {
     Args32 a;
     int rc = fill32(a, p, L, pack32_b, p ? p->dim_x - p->dim_y : 0);
     if (rc) return rc;
     if (!var_x || !u || !y || !hid_b || !eps_b || !y2 || !ent_part) return fail(-1, "null pointer");
     a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.y2_out = y2; a.part_out = ent_part;
+    a.h_all = h_all; a.fmv = fmv_b;
     const int P = 2 * p->recog_len;
     const int n0 = p->T / P + 1, n1 = (p->T + p->recog_len) / P + 1;       // as cbfssm_backward_pass_f64 counts them
     a.nseg0 = n0;
@@ -648,7 +670,7 @@ int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* 
 
 int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
-                            const double* y2, const double* eps_f, double* x, double* kl_part, void* stream)
+                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* kl_part, void* stream)
 {
     Args32 a;
     int rc = fill32(a, p, L, pack32_f, p ? p->dim_x : 0);
@@ -656,6 +678,7 @@ int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L
     if (!var_x || !var_y || !u || !y || !x || !kl_part || (p->dim_x > p->dim_y && !y2) || (p->T > 1 && !eps_f))
         return fail(-1, "null pointer");
     a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x; a.part_out = kl_part;
+    a.fmv = fmv_f;
     dim3 grid(unsigned((a.N + 15) / 16), 1);
     rc = dispatch32(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
     return rc ? fail(rc, "forward_pass_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;

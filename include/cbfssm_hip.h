@@ -306,7 +306,7 @@ int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* st
                               double* work, double* ginv_image, void* stream);
 
 /*
- * float32-ARITHMETIC variant of the forward evaluation (BASELINE.json configs[4]; the reference's model dtype argument,
+ * float32-ARITHMETIC variant of the forward evaluation and of the adjoint (BASELINE.json configs[4]; the reference's model dtype argument,
  * cbfssm.py:12: `CBFSSM(config, dtype=tf.float32)`).  As in the reference's float32 mode the Cholesky of K_mm is computed
  * in float64 and cast (gp_tf.py:57-65): the operands are the float64 pack of cbfssm_gp_prepare_f64 re-packed as float32
  * MFMA images; kernel tile, exp, the K^-1 K contraction (v_mfma_f32_16x16x4_f32) and the step epilogues are float32.
@@ -321,7 +321,18 @@ int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* st
  *                           also round the kernel tile to bfloat16, i.e. they evaluate the K^-1 K contraction with
  *                           bf16 operands and float32 accumulation (on the float32 MFMA: bf16 x bf16 products are exact in
  *                           float32).  A precision probe for the fp32-vs-bf16 tolerance sweep, not a throughput path.
- * Forward evaluation only: there is no float32 adjoint (training runs in float64).
+ *   fmv_* / h_all (may be NULL): what the float32 adjoint below reads of the forward evaluation -- every step's
+ *                           (fmean, fvar) and, for the backward runs, every step's output -- in the float64 buffers of
+ *                           cbfssm_backward_pass_f64 / cbfssm_forward_pass_f64 (same layout; float32 values).
+ *
+ * float32 ADJOINT (what `minimize` differentiates when the model dtype is float32, cbfssm.py:12,273-275): the reverse
+ * sweeps on v_mfma_f32_16x16x4_f32 with float32 accumulation over the time steps; the kernel tile and A2 = K^-1 k are
+ * recomputed (no saved tiles).  The partial slabs leave as float64 in the layout of the float64 adjoint for NON-stash tile
+ * heights -- [mubar | s2bar | Kinvbar (NBLK x NBLK C-layout images) | Zbar | small] = cbfssm_rev32_slab_elems doubles per
+ * workgroup, cbfssm_rev_workgroups workgroups -- so cbfssm_reduce_partials_f64 and cbfssm_train_tail_f64 (the K_mm ->
+ * Cholesky -> K^-1 adjoint stays float64, as the reference keeps the Cholesky in float64, gp_tf.py:57-65) take them as they
+ * are; for tile heights above 112 rows hand the Kinvbar section to cbfssm_train_tail_f64 as gB_dense_* with gB_ld = 0.
+ * Above 208 inducing points one call launches two passes over the time loop (half of the Kinvbar columns each).
  */
 int64_t cbfssm_pack_f32_elems(const cbfssm_pack_layout* layout);
 int cbfssm_gp_pack_f32(const cbfssm_pack_layout* layout, const double* pack, float* pack32, void* stream);
@@ -330,10 +341,19 @@ int cbfssm_gp_predict_f32(const cbfssm_pack_layout* layout, const float* pack32,
                           double* fmean, double* fvar, void* stream);
 int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const float* pack32_b,
                              const double* var_x, const double* u, const double* y, const double* hid_b,
-                             const double* eps_b, double* y2, double* ent_part, void* stream);
+                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* ent_part, void* stream);
 int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
-                            const double* y2, const double* eps_f, double* x, double* kl_part, void* stream);
+                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* kl_part, void* stream);
+int64_t cbfssm_rev32_slab_elems(const cbfssm_pack_layout* layout);
+int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
+                                const double* var_x, const double* var_y, const double* u, const double* y,
+                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, double cL,
+                                double* gy2, double* gpart, void* stream);
+int cbfssm_backward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const float* pack32_b,
+                                 const double* var_x, const double* u, const double* y, const double* hid_b,
+                                 const double* eps_b, const double* h_all, const double* fmv_b, const double* gy2, double cE,
+                                 double* gpart, void* stream);
 
 /*
  * ---- once-per-step tail of a train step ------------------------------------------------------------------------------

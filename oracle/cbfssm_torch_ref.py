@@ -56,8 +56,10 @@ class GPModel:
         self.num_points = zeta_pos.shape[0]
         self.out_dim = zeta_mean.shape[1]
         Kmm = self.kern.K(zeta_pos)                                                      # :129
-        Kmm = Kmm + JITTER * torch.eye(self.num_points, dtype=Kmm.dtype)                 # :52-54
-        self.cholesky = torch.linalg.cholesky(Kmm)                                       # :130
+        # cast_cholesky (gp_tf.py:57-65): the factorisation runs in float64 whatever the model dtype, then casts back
+        Kmm64 = Kmm.to(torch.float64)                                                    # :59-60
+        Kmm64 = Kmm64 + JITTER * torch.eye(self.num_points, dtype=torch.float64)         # :52-54
+        self.cholesky = torch.linalg.cholesky(Kmm64).to(Kmm.dtype)                       # :130, :62-64
 
     def predict(self, Xnew):
         Kmn = self.kern.K(self.zeta_pos, Xnew)                                           # :134
@@ -171,12 +173,13 @@ def elbo_step(config, params, u, y, noise, condition=True, want_pred=False):
     return out
 
 
-def loss_and_grads(config, params_np, u_np, y_np, noise_np, condition=True):
-    """Loss and d loss / d(12 unconstrained tensors) by reverse-mode autodiff, float64 on CPU."""
-    params = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params_np.items()}
-    u = torch.tensor(u_np, dtype=torch.float64)
-    y = torch.tensor(y_np, dtype=torch.float64)
-    noise = {k: torch.tensor(v, dtype=torch.float64) for k, v in noise_np.items()}
+def loss_and_grads(config, params_np, u_np, y_np, noise_np, condition=True, dtype=torch.float64):
+    """Loss and d loss / d(12 unconstrained tensors) by reverse-mode autodiff on the CPU; dtype = torch.float32 is the
+    reference's float32 model (cbfssm.py:12: every tensor float32, the Cholesky through float64, gp_tf.py:57-65)."""
+    params = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in params_np.items()}
+    u = torch.tensor(u_np, dtype=dtype)
+    y = torch.tensor(y_np, dtype=dtype)
+    noise = {k: torch.tensor(v, dtype=dtype) for k, v in noise_np.items()}
     out = elbo_step(config, params, u, y, noise, condition)
     out['loss'].backward()
     grads = {k: v.grad.detach().numpy().copy() for k, v in params.items()}

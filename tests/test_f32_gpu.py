@@ -22,8 +22,8 @@ def test_gp_predict_f32_every_tile_height(M, dim_x, dim_u, dim_y):
     w = syn.tiny(M=M, dim_x=dim_x, dim_u=dim_u, dim_y=dim_y)
     p = syn.perturb_params(syn.make_params(w, seed=M))
     rng = np.random.default_rng(7)
-    for g, Do in (('f', dim_x), ('b', dim_x - dim_y)):
-        pack = ops.GPPack(M, w.D, Do, DEV, 'dense').prepare(*[torch.tensor(a, device=DEV) for a in _gp_args(p, g)])
+    for g, Do, form in (('f', dim_x, 'dense'), ('b', dim_x - dim_y, 'dense'), ('f', dim_x, 'tri'), ('b', dim_x - dim_y, 'tri')):
+        pack = ops.GPPack(M, w.D, Do, DEV, form).prepare(*[torch.tensor(a, device=DEV) for a in _gp_args(p, g)])
         for npts in (1, 16, 37):
             X = torch.tensor(rng.standard_normal((npts, w.D)) * 1.5, device=DEV)
             fm, fv = pack.predict(X)
@@ -68,8 +68,92 @@ def test_elbo_f32_tracks_f64(kw, cond):
     assert torch.equal(out1, o32.out)
 
 
+GRAD_CASES = [
+    dict(M=12, dim_x=5, dim_u=2, dim_y=2, T=11, B=3, S=4, recog_len=3, k_factor=3.),                        # ragged chains, one row block
+    dict(M=24, dim_x=14, dim_u=7, dim_y=7, T=40, B=3, S=6, recog_len=16, k_factor=50., var_y=0.05 ** 2),    # Sarcos dims, two row blocks
+    dict(M=100, dim_x=14, dim_u=7, dim_y=7, T=20, B=2, S=20, recog_len=4, k_factor=50., var_y=0.05 ** 2),   # C3 tile (7 row blocks)
+    dict(M=130, dim_x=9, dim_u=3, dim_y=2, T=14, B=2, S=9, recog_len=3, k_factor=5.),                       # 10 row blocks (f64: stash mode)
+    dict(M=200, dim_x=14, dim_u=7, dim_y=7, T=9, B=1, S=20, recog_len=2, k_factor=50.),                     # C4 tile, two row blocks per wave
+    dict(M=300, dim_x=4, dim_u=2, dim_y=2, T=24, B=2, S=9, recog_len=5, k_factor=1.),                       # C5 tile: two passes over the time loop
+]
+
+
+@pytest.mark.parametrize('form', ['tri', 'dense'])
+@pytest.mark.parametrize('kw', GRAD_CASES)
+def test_f32_adjoint_matches_f64_adjoint_and_f32_restatement(kw, form):
+    """The float32 adjoint (cbfssm_*_pass_bwd_f32; what `minimize` differentiates for CBFSSM(config, dtype=float32),
+    cbfssm.py:12,273-275) at every tile height: all twelve gradients against (a) the float64 HIP adjoint on the same
+    inputs and (b) the PyTorch-CPU restatement run in float32 (every tensor float32, Cholesky through float64 as
+    gp_tf.py:57-65) -- PARITY UNPINNED like every oracle comparison here (no TensorFlow, no reference fixtures).
+    Both GP forms: 'tri' (the default of a float32 engine: every product with K^-1 as two triangular products, the
+    reference's order) and 'dense' (explicit K^-1).  Tolerance: 2e-3 of each tensor's largest entry against float64 for the
+    two-triangular form (float32 rounding through a T-step recurrence and its reverse sweep; achieved values are printed),
+    1e-2 for the dense form (it loses cond(K_mm) eps_32 per product: 2.6e-3 at the M = 300 case, where the inducing inputs
+    are dense in six dimensions).  Where K_mm is well conditioned (cond < 1e3) the two-triangular kernel must also be as
+    close to float64 as the float32 CPU restatement is, within a factor 20; above that the hand-derived adjoint is noisier
+    than autodiff through the two solves by construction -- it accumulates d loss / d K^-1 over all steps (in float32
+    here) and the float64 tail maps it to d loss / d K_mm = -K^-1 (.) K^-1, which amplifies the accumulator's rounding by
+    up to cond(K_mm): 1.6e-3 at the M = 300 case against 1.5e-5 for the restatement."""
+    from cbfssm.hip import train
+    from oracle import cbfssm_torch_ref as tref
+    w = syn.tiny(loss_factors=(2., 0.7), **kw)
+    cfg = w.model_config()
+    cfg['gp_form'] = form
+    p = syn.perturb_params(syn.make_params(w, seed=1), scale=0.1)
+    u, y = syn.make_inputs(w, seed=0)
+    noise = syn.make_noise(w, seed=2)
+    params = {k: torch.tensor(v, device=DEV) for k, v in p.items()}
+    l64, g64, _ = train.HipElboGrad(cfg, DEV).loss_and_grads(params, u, y, noise)
+    g64 = {k: v.cpu().numpy().copy() for k, v in g64.items()}
+    e32 = train.HipElboGrad(cfg, DEV, dtype='float32')
+    l32, g32, t32 = e32.loss_and_grads(params, u, y, noise)
+    assert float(t32['info']) == 0.0 and e32.pack_f.gp_form() == form
+    g32 = {k: v.cpu().numpy().copy() for k, v in g32.items()}
+    # a second evaluation is bit-identical (fixed-order reductions, no atomics)
+    _, g32b, _ = e32.loss_and_grads(params, u, y, noise)
+    for k in train.PARAM_NAMES:
+        assert np.array_equal(g32[k], g32b[k].cpu().numpy()), k
+    _, gt32 = tref.loss_and_grads(cfg, p, u, y, noise, True, dtype=torch.float32)
+    assert float(l32) == pytest.approx(float(l64), rel=2e-4)
+    from cbfssm.hip import lib as _lib
+    cond = max(float(e32.pack_f.scal[_lib.SCAL_COND]), float(e32.pack_b.scal[_lib.SCAL_COND]))
+    worst = {}
+    for k in train.PARAM_NAMES:
+        scale = np.abs(g64[k]).max()
+        e_hip = np.abs(g32[k] - g64[k]).max() / scale
+        e_cpu = np.abs(gt32[k].astype(np.float64) - g64[k]).max() / scale
+        worst[k] = (e_hip, e_cpu)
+        assert e_hip <= (2e-3 if form == 'tri' else 1e-2), (k, e_hip, e_cpu)
+        if form == 'tri' and cond < 1e3:
+            assert e_hip <= 20.0 * max(e_cpu, 1e-6), (k, e_hip, e_cpu)
+    print('\nfloat32 adjoint (%s form) M=%d T=%d cond %.1e: worst |g32 - g64| / max|g64| HIP %.1e, CPU float32 restatement %.1e'
+          % (form, w.M, w.T, cond, max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
+
+
+def test_f32_train_steps_track_f64():
+    """Three Adam steps (HipTrainStep: HIP graph, TF-1.8 update rule) of a float32 engine next to a float64 one from the same
+    initial values and noise: the parameters stay together to float32 accuracy."""
+    from cbfssm.hip.train import HipTrainStep, PARAM_NAMES
+    w = syn.tiny(M=20, T=13, B=2, S=8)
+    cfg = w.model_config()
+    p = syn.perturb_params(syn.make_params(w))
+    u, y = syn.make_inputs(w)
+    params = {k: torch.tensor(v, device=DEV) for k, v in p.items()}
+    s64 = HipTrainStep(cfg, params, DEV)
+    s32 = HipTrainStep(cfg, params, DEV, dtype='float32')
+    for k in range(3):
+        noise = syn.make_noise(w, seed=10 + k)
+        a = float(s64.step(u, y, noise))
+        b = float(s32.step(u, y, noise))
+        assert b == pytest.approx(a, rel=1e-3)
+    for k in PARAM_NAMES:
+        x64, x32 = s64.params[k].cpu().numpy(), s32.params[k].cpu().numpy()
+        assert np.abs(x32 - x64).max() <= 2e-3 * max(np.abs(x64).max(), 1e-3), k
+
+
 def test_f32_model_surface(tmp_path):
-    """CBFSSM(config, dtype='float32') (cbfssm.py:12): loss and predictions through the float32 passes; train raises"""
+    """CBFSSM(config, dtype='float32') (cbfssm.py:12): loss, predictions and `sess.run(model.train)` through the float32
+    passes and the float32 adjoint"""
     from cbfssm.datasets import make_synthetic_ds
     from cbfssm.model import CBFSSM
     from cbfssm.model.session import Session
@@ -87,10 +171,11 @@ def test_f32_model_surface(tmp_path):
             sess.run(m.init)
             m.load_ds(sess, ds.train_in_batch, ds.train_out_batch)
             res[dt] = m.run(sess, (m.loss, m.pred_mean), {m.condition: True})
-            if dt == 'float32':
-                m.load_ds(sess, ds.train_in_batch, ds.train_out_batch)
-                with pytest.raises(NotImplementedError):
-                    sess.run((m.train, m.loss), feed_dict={m.condition: True})
+            # one epoch of training (training/trainer.py:39-41): the losses of the two dtypes stay together
+            m.load_ds(sess, ds.train_in_batch, ds.train_out_batch)
+            res[dt + '_train'] = m.run(sess, (m.train, m.loss), {m.condition: True})[1]
+    assert np.all(np.isfinite(res['float32_train']))
+    np.testing.assert_allclose(res['float32_train'], res['float64_train'], rtol=5e-3)
     np.testing.assert_allclose(res['float32'][0], res['float64'][0], rtol=1e-3)
     np.testing.assert_allclose(res['float32'][1], res['float64'][1], rtol=0, atol=5e-3 * np.abs(res['float64'][1]).max())
 
