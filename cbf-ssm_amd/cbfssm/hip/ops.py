@@ -25,16 +25,20 @@ def _f64(t, device):
     return torch.as_tensor(t, dtype=torch.float64, device=device).contiguous()
 
 
+F32_FORM_COND = 1e3
+
+
 def gp_form_mode_f32(config=None, bf16=False):
-    """GP form of a float32 engine: 'tri' (the reference's two triangular products, gp_tf.py:137-145) unless 'dense' is asked
-    for (config['gp_form'] / CBFSSM_GP_FORM = dense).  In float32 the dense form's fvar_0 = sigma^2 - k.(K^-1 k) cancels to
-    cond eps_32 (measured at the C5 shape, round 2: pred_var 1.6 % off at cond 9e5, 20 % at cond 5e7), the sum of squares
-    sigma^2 - |L^-1 k|^2 does not -- and it is what a float32 model of the reference computes.  The bf16-operand probe
-    rounds the operands of the dense contraction and stays dense."""
+    """GP form policy of a float32 engine: the float64 one ('dense' | 'tri' | 'auto', default auto) with the automatic
+    switch to the reference's two triangular products (gp_tf.py:137-145) at cond(K_mm + jitter I) > 1e3 instead of 1e5
+    (`F32_FORM_COND`; GPPack.cond_threshold): in float32 the dense form's fvar_0 = sigma^2 - k.(K^-1 k) cancels to
+    cond eps_32, the sum of squares sigma^2 - |L^-1 k|^2 does not.  Measured at the C5 shape against float64 (pred_var):
+    cond 9e5: dense 1.6e-2, two-triangular 9.5e-3; cond 5e7: 0.21 / 0.24 -- past cond ~1e5 float32 itself (fmean carries
+    cond eps_32 in either form and the recurrence amplifies it over 1000 steps) is the limit, not the form.  The bf16-operand
+    probe rounds the operands of the dense contraction and stays dense."""
     if bf16:
         return 'dense'
-    mode = gp_form_mode(config)
-    return 'dense' if mode == 'dense' else 'tri'
+    return gp_form_mode(config)
 
 
 def gp_form_mode(config=None):
@@ -61,20 +65,22 @@ class GPPack:
         self.form_mode = form_mode or gp_form_mode()
         self.cond_threshold = float(os.environ.get('CBFSSM_GP_FORM_COND', 1e5))
         self.layout.gp_form = _l.GP_FORM_TRI if self.form_mode == 'tri' else _l.GP_FORM_DENSE
-        self._cond_host = None          # pinned landing slot of the asynchronous condition-number read-back
-        self._cond_ev = None
+        self._cond_host = None          # pinned landing slots of the asynchronous condition-number read-backs
         self._decided = self.form_mode != 'auto'
         self.last_cond = None
 
     # ---- form policy (auto mode).  The condition number comes out of the prepare kernel on the device; reading it is an
-    # asynchronous copy into pinned memory, consumed when its event has completed -- by the time the parameters have
-    # moved enough to matter that is a step or two late, and no step waits for the host.  Only the very first decision
-    # blocks (there is nothing older to go by).
+    # asynchronous copy into pinned memory.  The lag is DETERMINISTIC: the call of step k starts the read-back of step k's
+    # prepare and consumes the one started at step k - LAG (waiting on that event: two steps old, it has completed long
+    # ago, so no step waits for the host) -- two identically seeded runs switch kernels in the same step, and so do the
+    # ranks of a data-parallel run (same parameters => same condition numbers => same decision, no extra collective).
+    # Only the very first decision blocks (there is nothing older to go by).
+    LAG = 2
+
     def gp_form(self):
         return 'tri' if self.layout.gp_form == _l.GP_FORM_TRI else 'dense'
 
-    def _consume_cond(self):
-        cond = float(self._cond_host[0])
+    def _consume_cond(self, cond):
         self.last_cond = cond
         thr = self.cond_threshold
         tri = self.layout.gp_form == _l.GP_FORM_TRI
@@ -85,24 +91,30 @@ class GPPack:
             tri = False
         self.layout.gp_form = _l.GP_FORM_TRI if tri else _l.GP_FORM_DENSE
         self._decided = True
-        self._cond_ev = None
 
     def update_form(self, blocking=False):
-        """Consume a completed condition-number read-back (it may flip the form), start the next one; returns the form
-        the next launches run.  `blocking`: wait for the read-back of the latest prepare."""
+        """Start the read-back of the latest prepare's condition number and consume the one that is LAG calls old (it may
+        flip the form); returns the form the next launches run.  `blocking`: wait for the read-back of the latest prepare."""
         if self.form_mode != 'auto' or torch.cuda.is_current_stream_capturing():
             return self.gp_form()
-        if self._cond_ev is not None and self._cond_ev.query():
-            self._consume_cond()
-        if self._cond_ev is None:
-            if self._cond_host is None:
-                self._cond_host = torch.zeros(1, dtype=torch.float64).pin_memory()
-            self._cond_host.copy_(self.scal[_l.SCAL_COND:_l.SCAL_COND + 1], non_blocking=True)
-            self._cond_ev = torch.cuda.Event()
-            self._cond_ev.record()
+        if self._cond_host is None:
+            self._cond_host = torch.zeros(self.LAG + 2, dtype=torch.float64).pin_memory()
+            self._cond_q = []           # [(slot, event)] oldest first
+            self._cond_slot = 0
+        slot = self._cond_slot
+        self._cond_slot = (slot + 1) % self._cond_host.numel()
+        self._cond_host[slot:slot + 1].copy_(self.scal[_l.SCAL_COND:_l.SCAL_COND + 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._cond_q.append((slot, ev))
         if blocking or not self._decided:
-            self._cond_ev.synchronize()
-            self._consume_cond()
+            ev.synchronize()
+            self._cond_q = []
+            self._consume_cond(float(self._cond_host[slot]))
+        elif len(self._cond_q) > self.LAG:
+            oslot, oev = self._cond_q.pop(0)
+            oev.synchronize()
+            self._consume_cond(float(self._cond_host[oslot]))
         return self.gp_form()
 
     def prepare(self, Z, lengthscales, variance, zeta_mean, zeta_var, jitter=_l.JITTER):
@@ -240,8 +252,10 @@ class TilePool:
         self.budget = None
         self.log = []
 
-    def get(self, n_f, n_b):
-        """views of n_f / n_b doubles (n_b = 0: no backward GP), or (None, None) when the tiles do not fit the budget"""
+    def get(self, n_f, n_b, reserve=0.0):
+        """views of n_f / n_b doubles (n_b = 0: no backward GP), or (None, None) when the tiles do not fit the budget.
+        `reserve`: bytes the caller still has to allocate after this (the rest of the workspace): they must fit next to
+        the tiles, or the very next allocation would fail instead of the adjoint falling back to recompute mode."""
         import warnings
         if self.bufs is not None and self.bufs[0].numel() >= n_f and (n_b == 0 or (self.bufs[1] is not None and
                                                                                   self.bufs[1].numel() >= n_b)):
@@ -251,7 +265,10 @@ class TilePool:
         have = 0 if self.bufs is None else 8.0 * (self.bufs[0].numel() + (self.bufs[1].numel() if self.bufs[1] is not None else 0))
         need = 8.0 * (n_f + n_b)
         free_now = torch.cuda.mem_get_info(self.device)[0]
-        if need > self.budget or (need > 0.9 * free_now and os.environ.get('CBFSSM_A2S_MAX_GB') is None):
+        # the budget covers everything the pool holds: the buffers a growth step retires stay allocated (captured graphs
+        # hold their addresses) and count; what is free must also hold the caller's remaining buffers
+        held = float(self.bytes())
+        if held + need > self.budget or need + reserve > 0.9 * free_now:
             msg = ('saved A2 tiles of this shape need %.2f GB, over the budget of %.2f GB (CBFSSM_A2S_MAX_GB): its adjoint '
                    'recomputes A2 (slower, same numbers)' % (need / 2 ** 30, self.budget / 2 ** 30))
             self.log.append(msg)
@@ -300,7 +317,9 @@ class ElboWorkspace:
             n_b = int(lib.cbfssm_saved_a2_elems(C.byref(p), C.byref(packs[1].layout), 1)) if packs[1] is not None else 0
             if pool is None:
                 pool = TilePool(device)
-            self.a2s_f, self.a2s_b = pool.get(n_f, n_b)        # views into the engine's one pool (or None, None)
+            # what this workspace allocates after the tiles: trajectories, (fmean, fvar), adjoint buffers, slabs / stash
+            reserve = 8.0 * T * N * (3 * p.dim_x + 8 * dob) + 2.0 * 2 ** 30
+            self.a2s_f, self.a2s_b = pool.get(n_f, n_b, reserve)     # views into the engine's one pool (or None, None)
         self.x = torch.zeros(T, N, p.dim_x, **f)
         self.ent_part = torch.zeros(self.n_ent, **f)
         self.kl_part = torch.zeros(self.n_kl, **f)
@@ -385,6 +404,8 @@ class HipElbo:
         mode = gp_form_mode(config) if not self.f32 else gp_form_mode_f32(config, self.bf16)
         self.pack_f = GPPack(self.M, D, self.dim_x, self.device, mode)
         self.pack_b = GPPack(self.M, D, self.dim_x - self.dim_y, self.device, mode)
+        if self.f32:
+            self.pack_f.cond_threshold = self.pack_b.cond_threshold = min(self.pack_f.cond_threshold, F32_FORM_COND)
         self._ws = {}
 
     def gp_form(self):

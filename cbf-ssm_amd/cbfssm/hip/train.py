@@ -101,6 +101,8 @@ class HipElboGrad:
         mode = ops.gp_form_mode(config) if not self.f32 else ops.gp_form_mode_f32(config)
         self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device, mode)
         self.pack_b = GPPack(self.M, self.D, self.dob, self.device, mode)
+        if self.f32:
+            self.pack_f.cond_threshold = self.pack_b.cond_threshold = min(self.pack_f.cond_threshold, ops.F32_FORM_COND)
         self.has_adjoint = all(pk.layout.rev_slab > 0 for pk in (self.pack_f, self.pack_b))
         # tile heights above 112 inducing points run the adjoint in "stash mode" (include/cbfssm_hip.h)
         self.stash = bool(self.pack_f.layout.rev_stash)

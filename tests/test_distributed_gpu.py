@@ -108,6 +108,53 @@ def test_data_parallel_step_graphs_equal_eager():
             np.testing.assert_array_equal(pg[k], out[0][True][1][k])
 
 
+def _fallback_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from cbfssm.hip import train
+        w, p, (u, y), noise = _case()
+        st = train.HipTrainStep(w.model_config(), {k: torch.tensor(v, device='cuda:0') for k, v in p.items()}, 'cuda:0', dist,
+                                graph=True)
+        if rank == 0:
+            uu, yy, nz, weight = u, y, noise, 1.0              # the whole mini-batch
+        else:
+            # an empty shard: the one-sequence stand-in joins the collective with weight 0 (model/cbfssm.py) ...
+            uu, yy, weight = u[:1], y[:1], 0.0
+            nz = {k: np.ascontiguousarray(v[:, :, :1] if k != 'eps_f' else v[:, :1]) for k, v in noise.items()}
+            # ... and this rank cannot capture
+
+            class _Broken:
+                def __init__(self, *a, **k):
+                    raise RuntimeError('capture refused (test)')
+            torch.cuda.graph = _Broken
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            loss = float(st.step(uu, yy, nz, weight=weight))
+        assert st.use_graph == (rank == 0)
+        out[rank] = (loss, {k: v.detach().cpu().numpy().copy() for k, v in st.params.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capture_failure_on_an_empty_shard_keeps_its_zero_weight():
+    """A data-parallel rank whose HIP-graph capture fails falls back to eager launches; when that rank holds an empty shard
+    (a one-sequence stand-in with weight 0) the fallback must keep the weight, or sequence 0 is counted twice."""
+    from cbfssm.hip import train
+    w, p, (u, y), noise = _case()
+    ref = train.HipTrainStep(w.model_config(), {k: torch.tensor(v, device='cuda:0') for k, v in p.items()}, 'cuda:0')
+    loss = float(ref.step(u, y, noise))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_fallback_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for rank in (0, 1):
+        assert out[rank][0] == pytest.approx(loss, rel=1e-10)
+        for k in train.PARAM_NAMES:
+            np.testing.assert_allclose(out[rank][1][k], ref.params[k].cpu().numpy(), rtol=1e-9, atol=1e-12)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # stash-mode tile (M > 112): the contracted K^-1-adjoint images ride in the same flat buffer -> still ONE all-reduce
 # ---------------------------------------------------------------------------------------------------------------------

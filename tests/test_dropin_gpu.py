@@ -50,3 +50,56 @@ def test_template_flow(tmp_path):
     trainer2 = Trainer(model, root_dir)
     trainer2.train(ds, 1, retrain=True)
     assert trainer2.train_all[0] < trainer.train_all[0]
+
+
+def test_batched_test_experiments_equal_the_reference_loop(monkeypatch):
+    """Outputs.test_mse runs all test experiments in ONE launch (CBFSSM.run_experiments) where the reference loops over
+    B = 1 `sess.run`s (outputs/outputs.py:121-133).  Same model, same seed, once per mode: the per-experiment predictive
+    means are bitwise equal (every experiment gets the noise the k-th run of the loop would have drawn, in the chain order
+    c = b S + s) and so is the RMSE."""
+    from cbfssm.datasets import make_synthetic_ds
+    from cbfssm.outputs import Outputs
+    from cbfssm.model import CBFSSM
+    from cbfssm.model.session import Session
+
+    ds_sel = make_synthetic_ds(dim_u=1, dim_y=1, n_train=200, n_test=400, seed=1)
+    dim_x = 3
+    cfg = {'ds': ds_sel, 'batch_size': 8, 'shuffle': 100, 'seed': 11, 'dim_x': dim_x, 'ind_pnt_num': 20, 'samples': 10,
+           'learning_rate': 0.05, 'loss_factors': np.asarray([1., 0.]), 'k_factor': 5., 'recog_len': 8, 'zeta_pos': 2.,
+           'zeta_mean': 0.05 ** 2, 'zeta_var': 0.01 ** 2, 'var_x': np.asarray([0.002 ** 2] * dim_x),
+           'var_y': np.asarray([1. ** 2] * dim_x), 'gp_var': 0.5 ** 2, 'gp_len': 2.}
+    ds = ds_sel(40, 20)
+    assert ds.test_in.shape[0] >= 3                      # several experiments, or the comparison is empty
+    res = {}
+    for mode in ('loop', 'batched'):
+        if mode == 'loop':
+            monkeypatch.setenv('CBFSSM_OUTPUTS_LOOP', '1')
+        else:
+            monkeypatch.delenv('CBFSSM_OUTPUTS_LOOP', raising=False)
+        np.random.seed(123)                              # the unseeded numpy initialisers of _setup_vars (gp_tf.py:112-118)
+        m = CBFSSM(dict(cfg))
+        out = Outputs('/tmp')
+        out.set_ds(ds)
+        out.model = m
+        preds = []
+        with m.graph.as_default(), Session() as sess:
+            sess.run(m.init)
+            if mode == 'loop':
+                for k in range(ds.test_in.shape[0]):
+                    m.load_ds(sess, ds.test_in[k:k + 1], ds.test_out[k:k + 1])
+                    preds.append(m.run(sess, m.pred_mean, {m.condition: False})[0])
+            else:
+                preds = [p[0] for p in m.run_experiments(sess, m.pred_mean, ds.test_in, ds.test_out, {m.condition: False})]
+        # ... and through Outputs.test_mse itself (fresh model of the same seed: the noise generator starts over)
+        np.random.seed(123)
+        m2 = CBFSSM(dict(cfg))
+        out.model = m2
+        with m2.graph.as_default(), Session() as sess:
+            sess.run(m2.init)
+            out._path = lambda name: os.path.join('/tmp', 'cbfssm_test_' + mode + '_' + name)
+            out.test_mse(sess)
+        res[mode] = (preds, out.last_rmse)
+    assert len(res['loop'][0]) == len(res['batched'][0])
+    for a, b in zip(res['loop'][0], res['batched'][0]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert res['loop'][1] == res['batched'][1]
