@@ -69,7 +69,9 @@ def test_batched_test_experiments_equal_the_reference_loop(monkeypatch):
            'zeta_mean': 0.05 ** 2, 'zeta_var': 0.01 ** 2, 'var_x': np.asarray([0.002 ** 2] * dim_x),
            'var_y': np.asarray([1. ** 2] * dim_x), 'gp_var': 0.5 ** 2, 'gp_len': 2.}
     ds = ds_sel(40, 20)
-    assert ds.test_in.shape[0] >= 3                      # several experiments, or the comparison is empty
+    # five test experiments of 80 steps (the synthetic set comes as one 400-step experiment)
+    ds.test_in = np.ascontiguousarray(ds.test_in.reshape(5, 80, -1))
+    ds.test_out = np.ascontiguousarray(ds.test_out.reshape(5, 80, -1))
     res = {}
     for mode in ('loop', 'batched'):
         if mode == 'loop':
@@ -89,7 +91,7 @@ def test_batched_test_experiments_equal_the_reference_loop(monkeypatch):
                     m.load_ds(sess, ds.test_in[k:k + 1], ds.test_out[k:k + 1])
                     preds.append(m.run(sess, m.pred_mean, {m.condition: False})[0])
             else:
-                preds = [p[0] for p in m.run_experiments(sess, m.pred_mean, ds.test_in, ds.test_out, {m.condition: False})]
+                preds = list(m.run_experiments(sess, m.pred_mean, ds.test_in, ds.test_out, {m.condition: False}))
         # ... and through Outputs.test_mse itself (fresh model of the same seed: the noise generator starts over)
         np.random.seed(123)
         m2 = CBFSSM(dict(cfg))
@@ -101,5 +103,5 @@ def test_batched_test_experiments_equal_the_reference_loop(monkeypatch):
         res[mode] = (preds, out.last_rmse)
     assert len(res['loop'][0]) == len(res['batched'][0])
     for a, b in zip(res['loop'][0], res['batched'][0]):
-        assert np.array_equal(np.asarray(a), np.asarray(b))
+        assert np.asarray(a).shape == np.asarray(b).shape and np.array_equal(np.asarray(a), np.asarray(b))
     assert res['loop'][1] == res['batched'][1]
