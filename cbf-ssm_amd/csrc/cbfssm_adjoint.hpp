@@ -141,7 +141,18 @@ constexpr int REV_XLATE = CBF_REV_XLATE;      // row blocks the extra wave takes
 #ifdef CBF_NO_XW          // diagnostic builds: the seven-wave form
 constexpr bool rev_extra_wave(int, bool) { return false; }
 #else
-constexpr bool rev_extra_wave(int nblk, bool stash) { return nblk == 7 && !stash; }
+// Stash-mode tiles get an extra wave too, with another job: it is the STASH WRITER.  It copies the two operand images of every
+// step (K^T right after barrier 1, A2bar^T after barrier 4) from the LDS tiles to HBM, so that the row-block waves issue
+// no global stores inside the time loop: vmcnt retires in order and counts stores, and at 256 VGPRs with two row blocks per
+// wave these kernels reload spilled registers all through a step -- every such reload was an `s_waitcnt vmcnt(0)` that also
+// waited for the step's stash stores to reach HBM (isa_wait_audit.py: `vmcnt(1): waits for 9 [WWWWWWWWS]`).  It lands on
+// the SIMD that carries the fewest row blocks.  C4 adjoints 9.80 / 13.78 -> 9.58 / 13.34 ms, train step 38.9 -> 38.0 ms.
+// Not at 16 row blocks: eight waves would become nine and the three-wave SIMD would cap everybody at 168 VGPRs.
+// (Measured and NOT kept, round 3: the same wave also taking over Zbar~ += Ebar x~^T for all row blocks through an Ebar
+// tile in LDS -- the row-block waves shed 32 accumulator VGPRs (spill slots 64 -> 48 / 34 -> 12) and 16 MFMAs per step, the
+// kernels did not move: 9.68 / 13.35 ms.  And kernel tiles kept by the forward evaluation for these tile heights, read back
+// instead of rebuilt: 10.9 / 15.9 ms loaded at the step top, 11.1 / 15.9 ms prefetched a step ahead -- slower both ways.)
+constexpr bool rev_extra_wave(int nblk, bool stash) { return stash ? (nblk != 16) : (nblk == 7); }
 #endif
 
 // KD: k-steps of the products whose k index is the GP output dimension (mu Fm, s2 Fv): 4 in general, 2 when the launcher
@@ -161,7 +172,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     constexpr int GPW = (NG + W - 1) / W;               // groups per wave in phase G
     constexpr int PD = 17;                              // padded row length of the LDS tiles
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
-    constexpr bool XW = rev_extra_wave(NBLK, STASH);
+    constexpr bool XW = rev_extra_wave(NBLK, STASH) && !STASH;
+    constexpr bool SW = rev_extra_wave(NBLK, STASH) && STASH;      // stash-writer wave
     constexpr int XCB = XW ? REV_XCB : 0;               // column blocks of Kinvbar accumulated by the extra wave
     constexpr int NCB = STASH ? 1 : NBLK - XCB;         // ... and by the wave that owns the row block
     constexpr bool ALL_OK = (NBLK % RB == 0);           // every wave owns RB real row blocks (no predicate around MFMAs)
@@ -548,6 +560,39 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
             return;
         }
     }
+    if constexpr (SW) {
+        if (w == W) {
+            __syncthreads();                                         // (the barrier in front of the step loop)
+            for (int step = 0; step < nsteps; ++step) {
+                const int64_t slot = wg_linear * a.chunk_steps + step;
+                double* pk = a.stash_k + slot * NBLK * 256 + l;
+                double* pa = a.stash_a + slot * NBLK * 256 + l;
+                __syncthreads();                                     // 1: kernel tile complete (intact until phase F)
+#pragma unroll 2
+                for (int rb = 0; rb < NBLK; ++rb) {
+                    double v[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) v[s] = Kt[(16 * rb + nl) * PD + 4 * s + g];      // B[k = chain][col m]
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) pk[rb * 256 + s * 64] = v[s];
+                }
+                __syncthreads();                                     // 4: every A2bar row is written (intact until the
+                                                                     //    next step's phase E, behind its barrier 1)
+#pragma unroll 2
+                for (int rb = 0; rb < NBLK; ++rb) {
+                    double v[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) v[s] = A2t[(16 * rb + nl) * PD + 4 * s + g];     // A[row m][k = chain]
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) pa[rb * 256 + s * 64] = v[s];
+                }
+                if constexpr (PALIAS) __syncthreads();               // (the row-block waves: partial tiles over the K tile)
+                __syncthreads();                                     // 5
+                __syncthreads();                                     // 6
+            }
+            return;
+        }
+    }
     CBF_STAMP_DECL;
     double hcur[QPW];
     if (nsteps > 0) {
@@ -816,7 +861,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                     gMu[i] = CBF_MFMA(a2T[s], fmT[s], gMu[i]);                  // mubar[m][d] += A2[m][n] Fm[d][n]
                     gS2[i] = CBF_MFMA(a2T[s] * a2T[s], fvT[s], gS2[i]);         // s2bar[m][d] += A2[m][n]^2 Fv[d][n]
                 }
-                if constexpr (STASH) {
+                if constexpr (STASH && SW) {
+                    // (the stash-writer wave copies both operand images of this step from the LDS tiles)
+                } else if constexpr (STASH) {
                     // A2bar^T and K^T of this row block as the MFMA operand images of Kinvbar += A2bar K^T (exactly
                     // what the in-register variant below feeds its MFMAs): slot = (workgroup, step), per slot and
                     // row block 4 x 64 doubles each; cbfssm_stash_contract_f64 contracts them after the launch
