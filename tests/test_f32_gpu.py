@@ -71,9 +71,11 @@ def test_elbo_f32_tracks_f64(kw, cond):
 GRAD_CASES = [
     dict(M=12, dim_x=5, dim_u=2, dim_y=2, T=11, B=3, S=4, recog_len=3, k_factor=3.),                        # ragged chains, one row block
     dict(M=24, dim_x=14, dim_u=7, dim_y=7, T=40, B=3, S=6, recog_len=16, k_factor=50., var_y=0.05 ** 2),    # Sarcos dims, two row blocks
+    dict(M=50, dim_x=4, dim_u=1, dim_y=1, T=25, B=3, S=11, recog_len=4, k_factor=100., gp_len=2.),          # four row blocks (C2 tile)
     dict(M=100, dim_x=14, dim_u=7, dim_y=7, T=20, B=2, S=20, recog_len=4, k_factor=50., var_y=0.05 ** 2),   # C3 tile (7 row blocks)
     dict(M=130, dim_x=9, dim_u=3, dim_y=2, T=14, B=2, S=9, recog_len=3, k_factor=5.),                       # 10 row blocks (f64: stash mode)
     dict(M=200, dim_x=14, dim_u=7, dim_y=7, T=9, B=1, S=20, recog_len=2, k_factor=50.),                     # C4 tile, two row blocks per wave
+    dict(M=250, dim_x=4, dim_u=2, dim_y=2, T=12, B=2, S=9, recog_len=50, k_factor=1.),                      # 16 row blocks: two passes, T < R
     dict(M=300, dim_x=4, dim_u=2, dim_y=2, T=24, B=2, S=9, recog_len=5, k_factor=1.),                       # C5 tile: two passes over the time loop
 ]
 
