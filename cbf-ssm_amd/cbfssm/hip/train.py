@@ -282,9 +282,9 @@ class HipElboGrad:
         red = self.red
         sf, sb = self.slab_f, self.slab_b
         gB_f = gB_b = None
-        split = self._split(prob) if not self.f32 else None
+        split = self._split(prob) if not self.f32 else self._split(prob, adjoint=False)
         if self.f32:
-            gB_f, gB_b = self._adjoint_f32(prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red)
+            gB_f, gB_b = self._adjoint_f32(prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red, split)
         elif not self.stash and split is not None:
             self._adjoint_split(prob, split, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE)
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
@@ -389,7 +389,7 @@ class HipElboGrad:
 
     def _elbo_forward(self, prob, ws, c, u, y, hid_b, eps_b, eps_f):
         lf = self.config['loss_factors']
-        split = self._split(prob, adjoint=False) if not self.f32 else None
+        split = self._split(prob, adjoint=False)
         if split is None:
             ops.elbo_forward(prob, self.pack_f, self.pack_b, c['var_x'], c['var_y'], u, y, hid_b, eps_b, eps_f, lf, ws,
                              f32=self.f32)
@@ -402,13 +402,26 @@ class HipElboGrad:
         lb, lf_ = C.byref(self.pack_b.layout), C.byref(self.pack_f.layout)
         e_eps = _ptr(eps_f) if eps_f.numel() else None
 
+        if self.f32:
+            b32b, b32f = (C.c_void_p(pk.pack_f32().data_ptr()) for pk in (self.pack_b, self.pack_f))   # (re-packed on s0)
+
         def bwd(q, st):
+            if self.f32:
+                _l.check(lib.cbfssm_backward_pass_f32(C.byref(q), lb, b32b, _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b),
+                                                      _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.fmv_b),
+                                                      _ptr(ws.ent_part), st), 'cbfssm_backward_pass_f32')
+                return
             _l.check(lib.cbfssm_backward_pass_f64(C.byref(q), lb, _ptr(self.pack_b.buf), _ptr(c['var_x']), _ptr(u), _ptr(y),
                                                   _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all),
                                                   _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.ent_part), st),
                      'cbfssm_backward_pass_f64')
 
         def fwd(q, st):
+            if self.f32:
+                _l.check(lib.cbfssm_forward_pass_f32(C.byref(q), lf_, b32f, _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y),
+                                                     _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.kl_part), st),
+                         'cbfssm_forward_pass_f32')
+                return
             _l.check(lib.cbfssm_forward_pass_f64(C.byref(q), lf_, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
                                                  _ptr(u), _ptr(y), _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f),
                                                  _ptr(ws.a2s_f), _ptr(ws.kl_part), st), 'cbfssm_forward_pass_f64')
@@ -461,7 +474,7 @@ class HipElboGrad:
         rbwd(p_rest, st0)
         s0.wait_event(e3)
 
-    def _adjoint_f32(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):
+    def _adjoint_f32(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red, split=None):
         """float32 adjoint (cbfssm_*_pass_bwd_f32): one call per direction (above 208 inducing points a call is two passes
         over the time loop), float64 slabs in the non-stash layout reduced by the float64 reduction.  For the tile heights
         whose float64 adjoint runs in stash mode the Kinvbar section of the reduced slab is handed to the train tail the
@@ -472,12 +485,38 @@ class HipElboGrad:
         b32f, b32b = self.pack_f.buf32, self.pack_b.buf32           # filled by the forward evaluation (ops.elbo_forward)
         sf, sb = self.slab_f, self.slab_b
         e_eps = _ptr(eps_f) if eps_f.numel() else None
-        _l.check(lib.cbfssm_forward_pass_bwd_f32(pb, C.byref(self.pack_f.layout), C.c_void_p(b32f.data_ptr()), _ptr(c['var_x']),
-                                                 _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f),
-                                                 cL, _ptr(ws.gy2), _ptr(ws.gpart_f), st), 'cbfssm_forward_pass_bwd_f32')
-        _l.check(lib.cbfssm_backward_pass_bwd_f32(pb, C.byref(self.pack_b.layout), C.c_void_p(b32b.data_ptr()), _ptr(c['var_x']),
-                                                  _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b), _ptr(ws.h_all), _ptr(ws.fmv_b),
-                                                  _ptr(ws.gy2), cE, _ptr(ws.gpart_b), st), 'cbfssm_backward_pass_bwd_f32')
+
+        def rfwd(q, stq):
+            _l.check(lib.cbfssm_forward_pass_bwd_f32(C.byref(q), C.byref(self.pack_f.layout), C.c_void_p(b32f.data_ptr()),
+                                                     _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2), e_eps,
+                                                     _ptr(ws.x), _ptr(ws.fmv_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), stq),
+                     'cbfssm_forward_pass_bwd_f32')
+
+        def rbwd(q, stq):
+            _l.check(lib.cbfssm_backward_pass_bwd_f32(C.byref(q), C.byref(self.pack_b.layout), C.c_void_p(b32b.data_ptr()),
+                                                      _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
+                                                      _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), stq),
+                     'cbfssm_backward_pass_bwd_f32')
+        if split is None:
+            rfwd(prob, st)
+            rbwd(prob, st)
+        else:
+            # the chain-group split of the float64 adjoint (_adjoint_split): a main piece of whole rounds over the CUs, the
+            # remainder's forward-pass adjoint next to the main piece's many-workgroup backward-run adjoint
+            main, rest = split
+            p_main, p_rest = self._sub_problem(prob, 0, main), self._sub_problem(prob, main, rest)
+            s0, s1 = torch.cuda.current_stream(), self._side_stream()
+            st0, st1 = C.c_void_p(s0.cuda_stream), C.c_void_p(s1.cuda_stream)
+            rfwd(p_main, st0)
+            e2 = torch.cuda.Event()
+            e2.record(s0)
+            rfwd(p_rest, st0)
+            s1.wait_event(e2)
+            rbwd(p_main, st1)
+            e3 = torch.cuda.Event()
+            e3.record(s1)
+            rbwd(p_rest, st0)
+            s0.wait_event(e3)
         if not self.stash:
             assert self.slab32_f == sf and self.slab32_b == sb
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')

@@ -81,6 +81,7 @@ struct Args32 {
     double* fmv;          // optional: (fmean, fvar) of every step, kept for the adjoint (PassArgs::fmv layout)
     double* h_all;        // optional (backward runs): every step's output of both runs
     int tri;              // 1: two-triangular GP form (layout->gp_form == CBFSSM_GP_FORM_TRI)
+    int group0;           // chain-group split: this launch covers the 16-chain groups [group0, group0 + gridDim.x)
     int nseg0;
     // predict
     const double* X;
@@ -98,8 +99,12 @@ struct Tile32 {
     static constexpr int QPW = (4 + W - 1) / W;
     static constexpr int LDS_FLOATS = DK * 64 + 2 * MP * 16 + W * 512;     // xq, K tile, A tile (two-triangular form), partials
 
+    // M <= 112 (one row block per wave): the K^-1 rows of the wave stay in VGPRs for the whole pass (28 registers in
+    // float32) -- no operand stream in the time loop
+    static constexpr bool BREG = (NBLK <= 7 && RB == 1);
     float Zreg[RB][DK];
     float czr[RB][4];
+    float Breg[BREG ? KS : 1];
     const float* Bp;
     const float* Wp;
     const float* WTp;
@@ -121,6 +126,11 @@ struct Tile32 {
             for (int s = 0; s < DK; ++s) Zreg[i][s] = ok ? pk.Zp[(rbc * DK + s) * 64 + l] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) czr[i][r] = ok ? pk.cz[16 * rbc + 4 * (l >> 4) + r] : -1e30f;   // C row = 4 g + r
+        }
+        if constexpr (BREG) {
+            const int rbc = min(w, NBLK - 1);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) Breg[s] = pk.Bp[(rbc * KS + s) * 64 + l];
         }
     }
 
@@ -167,7 +177,12 @@ struct Tile32 {
 #pragma unroll
         for (int i = 0; i < RB; ++i) { acc[i][0] = f4{0, 0, 0, 0}; acc[i][1] = f4{0, 0, 0, 0}; }
         float q = 0.0f;
-        if constexpr (!TRI) {
+        if constexpr (!TRI && BREG) {
+            if (w < NBLK) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc[0][s & 1] = CBF_MFMA32(Breg[s], Kt[64 * s + l], acc[0][s & 1]);
+            }
+        } else if constexpr (!TRI) {
 #pragma unroll 1
             for (int s0 = 0; s0 < KS; s0 += 4) {
                 float b[4], aop[RB][4];
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do;
     const int naux = a.D - Do;
-    const int gx = blockIdx.x;
+    const int gx = blockIdx.x + a.group0;
     const int c0 = gx * 16;
     const int G16 = (N + 15) >> 4;
 
@@ -592,7 +607,7 @@ static int fill32(Args32& a, const cbfssm_problem* p, const cbfssm_pack_layout* 
     if (!p || !L || !pack32) return fail(-1, "null pointer");
     if (p->B < 1 || p->S < 1 || p->T < 1 || p->recog_len < 1) return fail(-1, "B, S, T, recog_len must be >= 1");
     if (p->half) return fail(-1, "the float32 passes serve CBFSSM only");
-    if (p->ngroups > 0) return fail(-1, "the float32 passes take whole launches (no chain-group split)");
+    if (p->ngroups > 0 && (p->group0 < 0 || p->group0 + p->ngroups > (p->B * p->S + 15) / 16)) return fail(-1, "bad chain-group range");
     if (L->D != p->dim_x + p->dim_u || L->Do != Do || L->M != p->M) return fail(-1, "pack does not match the problem");
     memset(&a, 0, sizeof(a));
     a.pk = pack32_ptrs(L, pack32);
@@ -600,6 +615,7 @@ static int fill32(Args32& a, const cbfssm_problem* p, const cbfssm_pack_layout* 
     a.dim_x = p->dim_x; a.dim_u = p->dim_u; a.dim_y = p->dim_y; a.Do = Do; a.D = L->D;
     a.recog_len = p->recog_len; a.condition = p->condition; a.k_factor = float(p->k_factor);
     a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
+    a.group0 = p->ngroups > 0 ? p->group0 : 0;
     return 0;
 }
 
@@ -663,7 +679,7 @@ int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* 
     const int P = 2 * p->recog_len;
     const int n0 = p->T / P + 1, n1 = (p->T + p->recog_len) / P + 1;       // as cbfssm_backward_pass_f64 counts them
     a.nseg0 = n0;
-    dim3 grid(unsigned((a.N + 15) / 16), unsigned(n0 + n1));
+    dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), unsigned(n0 + n1));
     rc = dispatch32(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);
     return rc ? fail(rc, "backward_pass_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;
 }
@@ -679,7 +695,7 @@ int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L
         return fail(-1, "null pointer");
     a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x; a.part_out = kl_part;
     a.fmv = fmv_f;
-    dim3 grid(unsigned((a.N + 15) / 16), 1);
+    dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 1);
     rc = dispatch32(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
     return rc ? fail(rc, "forward_pass_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;
 }

@@ -47,6 +47,7 @@ struct Rev32Args {
     int cb0;               // first Kinvbar column block this launch accumulates
     int first;             // 1: this launch also produces every other adjoint (and the y2 adjoint); 0: Kinvbar columns only
     int tri;               // 1: the products with K^-1 run as two triangular products (layout->gp_form == CBFSSM_GP_FORM_TRI)
+    int group0, gtotal;    // chain-group split: this launch covers groups [group0, group0 + gridDim.x) of gtotal
 };
 
 // TRI: every product with K^-1 = W^T W (A2 = K^-1 K in phase C, K^-1 A2bar in phase F) runs as two triangular products
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
     const int naux = D - Do;
     const int dob = a.dim_x - a.dim_y;
-    const int gx = blockIdx.x;
+    const int gx = blockIdx.x + a.group0;
     const int c0 = gx * 16;
     const int c = min(c0 + nl, N - 1);
     const bool cvalid = (c0 + nl) < N;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     const int run = (MODE == MODE_BWD) ? int(blockIdx.y) : 0;
     const int R = a.recog_len, P = 2 * R;
     const int KSr = a.KSr;
-    const int64_t wg_linear = (int64_t(blockIdx.z) * gridDim.y + blockIdx.y) * gridDim.x + gx;
+    const int64_t wg_linear = (int64_t(blockIdx.z) * gridDim.y + blockIdx.y) * a.gtotal + gx;
     const bool first = a.first != 0;
 
     bool ok[RB];
@@ -107,8 +108,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
 #pragma unroll
         for (int r = 0; r < 4; ++r) czr[i][r] = a.pk.cz[16 * rbs[i] + 4 * g + r];
     }
-    const float sigma2 = a.pk.scal[0];
-    (void)sigma2;
+    // M <= 112 (one row block per wave), dense form: the K^-1 rows of the wave in VGPRs for the whole pass
+    constexpr bool BREG = (NBLK <= 7 && RB == 1 && !TRI);
+    float Breg[BREG ? KS : 1];
+    if constexpr (BREG) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) Breg[s] = a.pk.BpN[(int64_t(rbs[0]) * KS + s) * 64 + l];
+    }
 
     f4 gMu[RB], gS2[RB], gZ[RB][JB], gB[RB][NCB];
 #pragma unroll
@@ -349,7 +355,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
             f4 acc[RB][2];
 #pragma unroll
             for (int i = 0; i < RB; ++i) { acc[i][0] = f4{0, 0, 0, 0}; acc[i][1] = f4{0, 0, 0, 0}; }
-            if constexpr (!TRI) {
+            if constexpr (BREG) {
+                if (ok[0]) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) acc[0][s & 1] = CBF_MFMA32(Breg[s], X[(4 * s + g) * PD + nl], acc[0][s & 1]);
+                }
+            } else if constexpr (!TRI) {
 #pragma unroll 1
                 for (int s0 = 0; s0 < KSr; s0 += 4) {
                     float b[4], aop[RB][4];
@@ -724,7 +735,7 @@ static int fill_rev32(Rev32Args& a, const cbfssm_problem* p, const cbfssm_pack_l
     if (!p || !L || !pack32) return fail(-1, "null pointer");
     if (p->B < 1 || p->S < 1 || p->T < 1 || p->recog_len < 1) return fail(-1, "B, S, T, recog_len must be >= 1");
     if (p->half) return fail(-1, "the float32 passes serve CBFSSM only");
-    if (p->ngroups > 0) return fail(-1, "the float32 passes take whole launches (no chain-group split)");
+    if (p->ngroups > 0 && (p->group0 < 0 || p->group0 + p->ngroups > (p->B * p->S + 15) / 16)) return fail(-1, "bad chain-group range");
     if (L->D != p->dim_x + p->dim_u || L->Do != Do || L->M != p->M) return fail(-1, "pack does not match the problem");
     memset(&a, 0, sizeof(a));
     a.pk = pack32_ptrs(L, pack32);
@@ -734,6 +745,8 @@ static int fill_rev32(Rev32Args& a, const cbfssm_problem* p, const cbfssm_pack_l
     a.slab = slab32(L);
     a.KSr = (L->M + 3) / 4;
     a.tri = (L->gp_form == CBFSSM_GP_FORM_TRI);
+    a.gtotal = (a.N + 15) / 16;
+    a.group0 = p->ngroups > 0 ? p->group0 : 0;
     return 0;
 }
 
@@ -765,7 +778,7 @@ int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layou
     a.cL = float(cL); a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.x = x; a.y2 = y2; a.gy2 = gy2;
     a.gpart = gpart; a.fmv = fmv_f;
     const int ncb = rev32_ncb(L->NBLK);
-    dim3 grid(unsigned((a.N + 15) / 16), 1, 1);
+    dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 1, 1);
     for (int cb0 = 0; cb0 < L->NBLK; cb0 += ncb) {
         a.cb0 = cb0; a.first = (cb0 == 0);
         rc = dispatch_rev32(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
@@ -789,7 +802,7 @@ int cbfssm_backward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layo
     const int nchunk = int(cbfssm_rev_workgroups(p, 1) / (2 * ((int64_t(a.N) + 15) / 16)));      // as the float64 adjoint chunks
     a.seg0 = 0; a.seg1 = nseg; a.nchunk = nchunk < 1 ? 1 : (nchunk > nseg ? nseg : nchunk);
     const int ncb = rev32_ncb(L->NBLK);
-    dim3 grid(unsigned((a.N + 15) / 16), 2, unsigned(a.nchunk));
+    dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 2, unsigned(a.nchunk));
     for (int cb0 = 0; cb0 < L->NBLK; cb0 += ncb) {
         a.cb0 = cb0; a.first = (cb0 == 0);
         rc = dispatch_rev32(L->NBLK, L->DK, MODE_BWD, a, grid, (hipStream_t)stream);

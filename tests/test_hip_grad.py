@@ -172,9 +172,10 @@ def test_grad_stash_mode_matches_oracle(kw, gib):
     _check(grads, gref)
 
 
-def test_chain_group_split_is_bitwise_identical(monkeypatch):
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_chain_group_split_is_bitwise_identical(monkeypatch, dtype):
     """The two-stream chain-group split (hip/train.py:_split) must not change a single bit: chains are independent and
-    every partial sum keeps its slot."""
+    every partial sum keeps its slot.  (float32: the float32 passes and adjoint take chain-group ranges too.)"""
     w = syn.tiny(M=20, T=19, B=5, S=11, recog_len=3)          # 55 chains = 4 groups of 16 (last one ragged)
     cfg = w.model_config()
     p = syn.perturb_params(syn.make_params(w))
@@ -182,14 +183,14 @@ def test_chain_group_split_is_bitwise_identical(monkeypatch):
     noise = syn.make_noise(w)
     params = {k: torch.tensor(v, device=DEV) for k, v in p.items()}
     monkeypatch.setenv('CBFSSM_NO_SPLIT', '1')
-    eng = train.HipElboGrad(cfg, DEV)
+    eng = train.HipElboGrad(cfg, DEV, dtype=dtype)
     l0, g0, _ = eng.loss_and_grads(params, u, y, noise)
     le0, _, ws0 = eng.forward(params, u, y, noise)
     x0 = ws0.x.clone()
     monkeypatch.delenv('CBFSSM_NO_SPLIT')
     for main in (1, 3):
         monkeypatch.setenv('CBFSSM_SPLIT_MAIN', str(main))
-        eng2 = train.HipElboGrad(cfg, DEV)
+        eng2 = train.HipElboGrad(cfg, DEV, dtype=dtype)
         l1, g1, _ = eng2.loss_and_grads(params, u, y, noise)
         le1, _, ws1 = eng2.forward(params, u, y, noise)
         assert float(l1) == float(l0) and float(le1) == float(le0)
