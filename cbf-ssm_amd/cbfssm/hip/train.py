@@ -517,10 +517,24 @@ class HipElboGrad:
             e3.record(s1)
             rbwd(p_rest, st0)
             s0.wait_event(e3)
+        def to_kinv_adjoint(img, pack):
+            """The float32 adjoint accumulates G = K^-1 (d loss / d K^-1) K^-1 directly (cbfssm_rev32.hip, phase F); the
+            float64 tail expects d loss / d K^-1 = K G K with K = K_mm + jitter I (two M x M float64 products, in place in
+            the C-layout image)."""
+            nb, M = pack.layout.NBLK, pack.M
+            G = _unpack_c(img, nb, nb)[:M, :M]
+            K = pack.Kmm + pack.scal[_l.SCAL_JITTER] * torch.eye(M, dtype=torch.float64, device=self.device)
+            Bd = torch.zeros(16 * nb, 16 * nb, dtype=torch.float64, device=self.device)
+            Bd[:M, :M] = K @ G @ K
+            img.copy_(Bd.view(nb, 4, 4, nb, 16).permute(0, 3, 1, 2, 4).reshape(-1))
+
         if not self.stash:
             assert self.slab32_f == sf and self.slab32_b == sb
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
+            for lo, pack in ((0, self.pack_f), (sf, self.pack_b)):
+                nb = pack.layout.NBLK
+                to_kinv_adjoint(red[lo + 2 * nb * 256:lo + 2 * nb * 256 + nb * nb * 256], pack)
             return None, None
         if getattr(self, '_tmp32', None) is None:
             self._tmp32 = torch.zeros(self.slab32_f + self.slab32_b, dtype=torch.float64, device=self.device)
@@ -537,6 +551,8 @@ class HipElboGrad:
             img = red[io:io + nimg]
             img.copy_(t32[og:og + nimg])
             imgs.append(img)
+        to_kinv_adjoint(imgs[0], self.pack_f)
+        to_kinv_adjoint(imgs[1], self.pack_b)
         return imgs[0], imgs[1]
 
     def _adjoint_stash(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):

@@ -9,7 +9,8 @@
 //
 // Same step structure as rev_kernel (phases B, C, E, F, G, D between four workgroup barriers), written once for every
 // tile height, nothing kept by the forward evaluation except (fmean, fvar) and the trajectories: the kernel tile and A2
-// are recomputed.  The Kinvbar accumulator (NBLK^2 tiles of 4 VGPRs) stays in registers for the whole pass; above 13
+// are recomputed.  The accumulator of the K_mm adjoint's data part (NBLK^2 tiles of 4 VGPRs; see phase F: it holds
+// (K^-1 A2bar) A2^T, not A2bar K^T) stays in registers for the whole pass; above 13
 // row blocks a launch accumulates NCB of the NBLK column blocks and the host launches ceil(NBLK / NCB) passes (the later
 // ones repeat the sweep and write only their columns).  This is the path of a reduced-precision model, not the headline.
 //
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     float* Fm = A2t + MP * PD;                 // [16][17]
     float* Fv = Fm + 16 * PD;
     float* part = Fv + 16 * PD;                // [W][PSL]
-    float* At = part + W * PSL;                // [MP][17]  (TRI: rows of W K / W A2bar between the two triangular products)
+    float* A2k = part + W * PSL;               // [MP][17]  A2 rows of every wave, kept from phase E for the accumulation in F
+    float* At = A2k + MP * PD;                 // [MP][17]  (TRI: rows of W K / W A2bar between the two triangular products)
 
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
     const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
@@ -452,10 +454,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                 for (int r = 0; r < 4; ++r) a2bar[r] = T1[r] + 2.0f * a2[i][r] * T2[r] - kreg[i][r] * fvsum;
                 // 16 x 16 transposes through this wave's own rows of the A2bar tile: C layout (row 4 g + r, col nl) ->
                 // A-operand layout (row nl, k = 4 s + g)
-                float a2T[4], abT[4];
+                float a2T[4];
                 float* own = A2t + 16 * rbs[i] * PD;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) own[(4 * g + r) * PD + nl] = a2[i][r];
+                for (int r = 0; r < 4; ++r) {
+                    own[(4 * g + r) * PD + nl] = a2[i][r];
+                    A2k[(16 * rbs[i] + 4 * g + r) * PD + nl] = a2[i][r];
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int s = 0; s < 4; ++s) a2T[s] = own[nl * PD + 4 * s + g];
@@ -469,19 +474,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                         gS2[i] = CBF_MFMA32(a2T[s] * a2T[s], fvT[s], gS2[i]);           // s2bar[m][d] += A2[m][n]^2 Fv[d][n]
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int s = 0; s < 4; ++s) abT[s] = own[nl * PD + 4 * s + g];
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    if (a.cb0 + cb < NBLK) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const float kT = Kt[(16 * (a.cb0 + cb) + nl) * PD + 4 * s + g];
-                            gB[i][cb] = CBF_MFMA32(abT[s], kT, gB[i][cb]);              // Kinvbar[m'][m] += A2bar[m'][n] K[m][n]
-                        }
-                    }
-                }
             }
         }
         if (has_next) store_inputs(xqn, hnext, auxn);
@@ -492,6 +484,34 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         {
             f4 kb_[RB];
             kinv_times(A2t, kb_);                     // (TRI: the A tile was last read in phase C of every wave, before barrier 4)
+            // The K_mm adjoint's data part, accumulated as  G += (K^-1 A2bar) A2^T  (= K^-1 (A2bar K^T) K^-1, K^-1 being
+            // symmetric) instead of  d loss / d K^-1 += A2bar K^T: both factors are K^-1-applied already, so nothing
+            // multiplies the float32 accumulator by K^-1 from both sides afterwards (that amplified its rounding by
+            // cond(K_mm): 1.6e-3 on the gradient at cond 4e4).  The host hands K_mm' G K_mm' to the float64 tail, which
+            // expects d loss / d K^-1.  Transposes through this wave's own rows of the K tile (dead after phase E).
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                if (ok[i]) {
+                    float kbT[4];
+                    float* ownk = Kt + 16 * rbs[i] * PD;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ownk[(4 * g + r) * PD + nl] = kb_[i][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kbT[s] = ownk[nl * PD + 4 * s + g];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) {
+                        if (a.cb0 + cb < NBLK) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const float a2c = A2k[(16 * (a.cb0 + cb) + nl) * PD + 4 * s + g];
+                                gB[i][cb] = CBF_MFMA32(kbT[s], a2c, gB[i][cb]);        // G[m'][m] += (K^-1 A2bar)[m'][n] A2[m][n]
+                            }
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -673,7 +693,7 @@ static int launch_rev32(int mode, const Rev32Args& a, dim3 grid, hipStream_t st)
     constexpr int JB = (4 * DK + 1 + 15) / 16;
     constexpr int PSL = (JB > 2 ? JB : 2) * 256;
     constexpr int NCB = rev32_ncb(NBLK);
-    const size_t lds = size_t(2 * 4 * DK * 17 + (TRI ? 3 : 2) * 16 * NBLK * 17 + 2 * 16 * 17 + W * PSL) * sizeof(float);
+    const size_t lds = size_t(2 * 4 * DK * 17 + (TRI ? 4 : 3) * 16 * NBLK * 17 + 2 * 16 * 17 + W * PSL) * sizeof(float);
     hipError_t e = hipSuccess;
     if (mode == MODE_FWD) {
         auto k = rev32_kernel<NBLK, RB, DK, MODE_FWD, NCB, TRI>;

@@ -87,15 +87,13 @@ def test_f32_adjoint_matches_f64_adjoint_and_f32_restatement(kw, form):
     cbfssm.py:12,273-275) at every tile height: all twelve gradients against (a) the float64 HIP adjoint on the same
     inputs and (b) the PyTorch-CPU restatement run in float32 (every tensor float32, Cholesky through float64 as
     gp_tf.py:57-65) -- PARITY UNPINNED like every oracle comparison here (no TensorFlow, no reference fixtures).
-    Both GP forms: 'tri' (the default of a float32 engine: every product with K^-1 as two triangular products, the
-    reference's order) and 'dense' (explicit K^-1).  Tolerance: 2e-3 of each tensor's largest entry against float64 for the
-    two-triangular form (float32 rounding through a T-step recurrence and its reverse sweep; achieved values are printed),
-    1e-2 for the dense form (it loses cond(K_mm) eps_32 per product: 2.6e-3 at the M = 300 case, where the inducing inputs
-    are dense in six dimensions).  Where K_mm is well conditioned (cond < 1e3) the two-triangular kernel must also be as
-    close to float64 as the float32 CPU restatement is, within a factor 20; above that the hand-derived adjoint is noisier
-    than autodiff through the two solves by construction -- it accumulates d loss / d K^-1 over all steps (in float32
-    here) and the float64 tail maps it to d loss / d K_mm = -K^-1 (.) K^-1, which amplifies the accumulator's rounding by
-    up to cond(K_mm): 1.6e-3 at the M = 300 case against 1.5e-5 for the restatement."""
+    Both GP forms: 'tri' (what the automatic rule of a float32 engine runs above cond 1e3: every product with K^-1 as two
+    triangular products, the reference's order) and 'dense' (explicit K^-1).  Tolerance against float64: 2e-3 of each tensor's
+    largest entry (float32 rounding through a T-step recurrence and its reverse sweep; achieved values are printed; the dense
+    form loses cond(K_mm) eps_32 per product: 2.4e-4 at the M = 300 case, cond 4e4), and the two-triangular kernel must be as
+    close to float64 as the float32 CPU restatement is, within a factor 20, on every case -- ill-conditioned ones included: the
+    kernel accumulates (K^-1 A2bar) A2^T, so nothing multiplies a float32 accumulator by K^-1 from both sides (with the
+    d loss / d K^-1 accumulator of the float64 kernels it was 1.6e-3 at cond 4e4 against 2.5e-5 for the restatement)."""
     from cbfssm.hip import train
     from oracle import cbfssm_torch_ref as tref
     w = syn.tiny(loss_factors=(2., 0.7), **kw)
@@ -125,8 +123,8 @@ def test_f32_adjoint_matches_f64_adjoint_and_f32_restatement(kw, form):
         e_hip = np.abs(g32[k] - g64[k]).max() / scale
         e_cpu = np.abs(gt32[k].astype(np.float64) - g64[k]).max() / scale
         worst[k] = (e_hip, e_cpu)
-        assert e_hip <= (2e-3 if form == 'tri' else 1e-2), (k, e_hip, e_cpu)
-        if form == 'tri' and cond < 1e3:
+        assert e_hip <= 2e-3, (k, e_hip, e_cpu)
+        if form == 'tri':
             assert e_hip <= 20.0 * max(e_cpu, 1e-6), (k, e_hip, e_cpu)
     print('\nfloat32 adjoint (%s form) M=%d T=%d cond %.1e: worst |g32 - g64| / max|g64| HIP %.1e, CPU float32 restatement %.1e'
           % (form, w.M, w.T, cond, max(v[0] for v in worst.values()), max(v[1] for v in worst.values())))
