@@ -328,11 +328,15 @@ int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* st
  * float32 ADJOINT (what `minimize` differentiates when the model dtype is float32, cbfssm.py:12,273-275): the reverse
  * sweeps on v_mfma_f32_16x16x4_f32 with float32 accumulation over the time steps; the kernel tile and A2 = K^-1 k are
  * recomputed (no saved tiles).  The partial slabs leave as float64 in the layout of the float64 adjoint for NON-stash tile
- * heights -- [mubar | s2bar | Kinvbar (NBLK x NBLK C-layout images) | Zbar | small] = cbfssm_rev32_slab_elems doubles per
+ * heights -- [mubar | s2bar | G (NBLK x NBLK C-layout images) | Zbar | small] = cbfssm_rev32_slab_elems doubles per
  * workgroup, cbfssm_rev_workgroups workgroups -- so cbfssm_reduce_partials_f64 and cbfssm_train_tail_f64 (the K_mm ->
- * Cholesky -> K^-1 adjoint stays float64, as the reference keeps the Cholesky in float64, gp_tf.py:57-65) take them as they
- * are; for tile heights above 112 rows hand the Kinvbar section to cbfssm_train_tail_f64 as gB_dense_* with gB_ld = 0.
- * Above 208 inducing points one call launches two passes over the time loop (half of the Kinvbar columns each).
+ * Cholesky -> K^-1 adjoint stays float64, as the reference keeps the Cholesky in float64, gp_tf.py:57-65) take them, with ONE
+ * difference: the matrix section holds G = sum (K^-1 A2bar) A2^T = K^-1 (d loss / d K^-1) K^-1, the data part of the K_mm
+ * adjoint itself (a float32 accumulator of d loss / d K^-1 would have its rounding multiplied by K^-1 from both sides in the
+ * tail).  The tail expects d loss / d K^-1: replace the section by K G K, K = K_mm + jitter I (pack sections Kmm, scal), two
+ * M x M float64 products -- cbf-ssm_amd/cbfssm/hip/train.py:_adjoint_f32.  For tile heights above 112 rows hand that
+ * section to cbfssm_train_tail_f64 as gB_dense_* with gB_ld = 0.
+ * Above 208 inducing points one call launches two passes over the time loop (half of the columns of G each).
  */
 int64_t cbfssm_pack_f32_elems(const cbfssm_pack_layout* layout);
 int cbfssm_gp_pack_f32(const cbfssm_pack_layout* layout, const double* pack, float* pack32, void* stream);
