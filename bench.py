@@ -163,8 +163,8 @@ def main():
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'sample', 'full'])
     ap.add_argument('--params', default='init', choices=['init', 'trained'],
                     help='init: run-script initial values (cond(K_mm) 1..700, dense GP form).  trained: the trained-like '
-                         'family of the parity sweep (cbfssm.synthetic.trained_like_params, lengthscales x 32, inducing means '
-                         '0.1: cond 2e6, the two-triangular GP form a trained model runs in)')
+                         'family of the parity sweep (cbfssm.synthetic.trained_like_params, lengthscales x 64, inducing means '
+                         '0.1: cond 3e7, above the automatic switch to the two-triangular GP form)')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'],
                     help='float32: the float32-arithmetic passes and adjoint (NOT the headline: the reference computes in '
                          'float64)')
@@ -214,7 +214,7 @@ def main():
     u = torch.randn(w.B, w.T, w.dim_u, dtype=torch.float64, device=dev, generator=g)
     y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=dev, generator=g)
     if args.params == 'trained':
-        p_np = syn.trained_like_params(w, ls_mult=32.0, zeta_mean=0.1)
+        p_np = syn.trained_like_params(w, ls_mult=64.0, zeta_mean=0.1)
     else:
         p_np = syn.make_params(w, seed=1)
     params = {k: torch.tensor(v, device=dev) for k, v in p_np.items()}

@@ -30,7 +30,7 @@ F32_FORM_COND = 1e3
 
 def gp_form_mode_f32(config=None, bf16=False):
     """GP form policy of a float32 engine: the float64 one ('dense' | 'tri' | 'auto', default auto) with the automatic
-    switch to the reference's two triangular products (gp_tf.py:137-145) at cond(K_mm + jitter I) > 1e3 instead of 1e5
+    switch to the reference's two triangular products (gp_tf.py:137-145) at cond(K_mm + jitter I) > 1e3 instead of 3e7
     (`F32_FORM_COND`; GPPack.cond_threshold): in float32 the dense form's fvar_0 = sigma^2 - k.(K^-1 k) cancels to
     cond eps_32, the sum of squares sigma^2 - |L^-1 k|^2 does not.  Measured at the C5 shape against float64 (pred_var):
     cond 9e5: dense 1.6e-2, two-triangular 9.5e-3; cond 5e7: 0.21 / 0.24 -- past cond ~1e5 float32 itself (fmean carries
@@ -45,7 +45,13 @@ def gp_form_mode(config=None):
     """'dense' | 'tri' | 'auto' (config['gp_form'] or CBFSSM_GP_FORM; default auto): which form of GPModel.predict the pass
     kernels run.  dense: A2 = K^-1 k in one product, fvar_0 = sigma^2 - k.A2.  tri: the reference's own order
     (gp_tf.py:137-145), A = L^-1 k, fvar_0 = sigma^2 - |A|^2, A2 = L^-T A as two triangular products.  auto: dense while
-    the measured condition number of K_mm + jitter I stays below CBFSSM_GP_FORM_COND (1e5), tri above."""
+    the measured infinity-norm condition number of K_mm + jitter I (about 3.4 x the 2-norm one on the trained-like
+    family) stays below CBFSSM_GP_FORM_COND (3e7), tri above.  Where that number comes from: the dense form's
+    fvar_0 = sigma^2 - k.(K^-1 k) loses about 8e-14 x cond_2 of (fvar + var_x) near the inducing inputs (measured: 5.9e-9 at
+    1.1e5, 2.5e-7 at 2.4e6, 3.2e-6 at 4e7, 6.0e-6 at 2e8), the north_star tolerance is 1e-5: the switch
+    at cond_2 ~ 1e7 keeps the dense form ten times inside it, and through the full C3 recurrence the dense form is then
+    at 1.4e-8 on the predictive variance (cond 2e6).  Round 2 switched at 1e5, which ran every trained-like model 6-24 %
+    slower for digits nobody asked for."""
     mode = None
     if config is not None:
         mode = config.get('gp_form')
@@ -63,7 +69,7 @@ class GPPack:
         self.M, self.D, self.Do = M, D, Do
         self.buf = torch.zeros(self.layout.total, dtype=torch.float64, device=device)
         self.form_mode = form_mode or gp_form_mode()
-        self.cond_threshold = float(os.environ.get('CBFSSM_GP_FORM_COND', 1e5))
+        self.cond_threshold = float(os.environ.get('CBFSSM_GP_FORM_COND', 3e7))
         self.layout.gp_form = _l.GP_FORM_TRI if self.form_mode == 'tri' else _l.GP_FORM_DENSE
         self._cond_host = None          # pinned landing slots of the asynchronous condition-number read-backs
         self._decided = self.form_mode != 'auto'

@@ -109,7 +109,7 @@ def test_condition_estimate_and_automatic_form(monkeypatch):
     monkeypatch.setenv('CBFSSM_GP_FORM', 'auto')
     orc = _oracle()
     w = dataclasses.replace(syn.WORKLOADS['C3'], B=2, T=12)
-    for ls_mult, expect in ((1.0, 'dense'), (8.0, 'dense'), (32.0, 'tri'), (128.0, 'tri')):
+    for ls_mult, expect in ((1.0, 'dense'), (8.0, 'dense'), (32.0, 'dense'), (64.0, 'tri'), (128.0, 'tri')):
         p = syn.trained_like_params(w, ls_mult=ls_mult, zeta_mean=0.1)
         eng = ops.HipElbo(w.model_config(), DEV)
         eng.prepare(p)
