@@ -89,8 +89,9 @@ def test_f32_adjoint_matches_f64_adjoint_and_f32_restatement(kw, form):
     gp_tf.py:57-65) -- PARITY UNPINNED like every oracle comparison here (no TensorFlow, no reference fixtures).
     Both GP forms: 'tri' (what the automatic rule of a float32 engine runs above cond 1e3: every product with K^-1 as two
     triangular products, the reference's order) and 'dense' (explicit K^-1).  Tolerance against float64: 2e-3 of each tensor's
-    largest entry (float32 rounding through a T-step recurrence and its reverse sweep; achieved values are printed; the dense
-    form loses cond(K_mm) eps_32 per product: 2.4e-4 at the M = 300 case, cond 4e4), and the two-triangular kernel must be as
+    largest entry (float32 rounding through a T-step recurrence and its reverse sweep; achieved values are printed), 1e-2 for
+    the dense form (it loses cond(K_mm) eps_32 per product: 2.1e-3 at the M = 50 case, cond 1e5 -- which the automatic rule
+    of a float32 engine never runs dense), and the two-triangular kernel must be as
     close to float64 as the float32 CPU restatement is, within a factor 20, on every case -- ill-conditioned ones included: the
     kernel accumulates (K^-1 A2bar) A2^T, so nothing multiplies a float32 accumulator by K^-1 from both sides (with the
     d loss / d K^-1 accumulator of the float64 kernels it was 1.6e-3 at cond 4e4 against 2.5e-5 for the restatement)."""
@@ -123,7 +124,7 @@ def test_f32_adjoint_matches_f64_adjoint_and_f32_restatement(kw, form):
         e_hip = np.abs(g32[k] - g64[k]).max() / scale
         e_cpu = np.abs(gt32[k].astype(np.float64) - g64[k]).max() / scale
         worst[k] = (e_hip, e_cpu)
-        assert e_hip <= 2e-3, (k, e_hip, e_cpu)
+        assert e_hip <= (2e-3 if form == 'tri' else 1e-2), (k, e_hip, e_cpu)
         if form == 'tri':
             assert e_hip <= 20.0 * max(e_cpu, 1e-6), (k, e_hip, e_cpu)
     print('\nfloat32 adjoint (%s form) M=%d T=%d cond %.1e: worst |g32 - g64| / max|g64| HIP %.1e, CPU float32 restatement %.1e'
