@@ -71,6 +71,7 @@ struct PrepArgs {
     double* WTp;
     double* info_out;      // kmm_chol: 1 double
     const double* Kin;     // cbfssm_cholesky_f64: factorise this M x M matrix instead of building K(Z, Z)
+    double refine_cond;    // condition number above which G = L^-T gets its Newton step (refine_threshold())
 };
 
 struct PrepArgs2 {
@@ -80,9 +81,19 @@ struct PrepArgs2 {
 #define PREP_NT 1024
 #define PREP_NB 32
 #define PREP_LDS_MAX_M 140
-#ifndef CBF_REFINE_COND
-#define CBF_REFINE_COND 1e4   // infinity-norm condition number of K_mm + jitter I above which G = L^-T gets its Newton step
-#endif   // (M | 1) * M doubles must fit the 160 KiB LDS next to the small arrays
+// Infinity-norm condition number of K_mm + jitter I above which G = L^-T gets its Newton step in doubled precision.  The
+// left residual of W = L^-1 matters where the kernels multiply by W -- the two-triangular GP form, which the Python surface
+// runs above 3e7 and keeps down to a quarter of that (hysteresis) -- so the default is that lower edge; below it the
+// dense form's K^-1 = G G^T is used, whose error is the cancellation in sigma^2 - k.(K^-1 k), not the factor's.
+// CBFSSM_REFINE_COND overrides (0: always).  Cost when it runs: 0.07 ms at M = 100, 0.5 ms at M = 200, 1.9 ms at M = 300.
+static double refine_threshold()
+{
+    static const double v = [] {
+        const char* e = getenv("CBFSSM_REFINE_COND");
+        return e ? atof(e) : 7.5e6;
+    }();
+    return v;
+}   // (M | 1) * M doubles must fit the 160 KiB LDS next to the small arrays
 
 // One workgroup per GPModel (blockIdx.x).  The working matrix W (row stride LD, odd) starts as
 //   lower triangle + diagonal: K_mm + jitter I ;  strict upper triangle: 0 (the off-diagonal of the bordering identity)
@@ -351,38 +362,89 @@ __global__ __launch_bounds__(PREP_NT) void prepare_kernel(PrepArgs2 aa)
     // doubled precision (compensated dot products: exact products by FMA, two-sum accumulation) squares the residual
     // (1e-11 -> 1e-22): W becomes the correctly rounded inverse of the L written above, and W k is then as accurate
     // as the substitution.  Runs above CBF_REFINE_COND only (a uniform branch on the measured condition number).
-    if (s_cond > CBF_REFINE_COND && s_info == 0 && a.Bp) {
+    if (s_cond > a.refine_cond && s_info == 0 && a.Bp) {
         double* Rg = a.Kinv;        // scratch until K^-1 is rebuilt: lower + diagonal = R, strict upper = the correction of G
         double* cdiag = a.Bp;       // (diagonal of the correction: the image section is written further down)
         {
 #pragma clang fp contract(off)
-            for (int idx = tid; idx < M * M; idx += PREP_NT) {
-                const int i = idx / M, j = idx - i * M;
-                if (j > i) continue;
-                // R[i][j] = delta_ij - sum_{k=j..i} L[i][k] W[k][j],  W[k][j] = G[j][k],  L[i][i] = sqrt(piv_i)
-                double s = (i == j) ? 1.0 : 0.0, c = 0.0;
-                for (int k = j; k <= i; ++k) {
-                    const double lv = (k == i) ? sqrt(piv[i]) : Wm[i * LD + k];
-                    const double gv = Wm[j * LD + k];
-                    const double p = -(lv * gv);
-                    const double e = __builtin_fma(-lv, gv, -p);     // exact: lv gv = -(p + e)
-                    const double t = s + p;
-                    const double z = t - s;
-                    c += ((s - (t - z)) + (p - z)) + e;               // two-sum error of s + p, plus the product's
-                    s = t;
+            // four rows of one column per thread: four independent compensated sums (one alone is a chain of six dependent
+            // float64 additions per term), the W operand shared
+            const int NG4 = (M + 3) >> 2;
+            for (int idx = tid; idx < NG4 * M; idx += PREP_NT) {
+                const int ig = idx / M, j = idx - ig * M;
+                const int i0 = 4 * ig;
+                if (j > i0 + 3 || j >= M) continue;
+                const int ihi = min(i0 + 3, M - 1);
+                double s[4], c[4], dg[4];
+                int row[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[r] = (i0 + r == j) ? 1.0 : 0.0;
+                    c[r] = 0.0;
+                    row[r] = min(i0 + r, M - 1) * LD;                 // (rows beyond M: a copy of the last row, dropped below)
+                    dg[r] = sqrt(piv[min(i0 + r, M - 1)]);            // L[i][i]
                 }
-                const double r = s + c;
-                Rg[i * M + j] = r;
+                auto term = [&](int r, double lv, double gv) {
+                    const double p = -(lv * gv);
+                    const double e = __builtin_fma(-lv, gv, -p);       // exact: lv gv = -(p + e)
+                    const double t = s[r] + p;
+                    const double z = t - s[r];
+                    c[r] += ((s[r] - (t - z)) + (p - z)) + e;          // two-sum error of s + p, plus the product's
+                    s[r] = t;
+                };
+                // k < i0: strictly below the diagonal for all four rows -- no predicates in the loop
+                int k = j;
+                for (; k < i0; ++k) {
+                    const double gv = Wm[j * LD + k];                 // G[j][k] = W[k][j]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) term(r, Wm[row[r] + k], gv);
+                }
+                // the diagonal block: L[i][k] for k <= i, L[i][i] = sqrt(piv_i), zero above
+                for (; k <= ihi; ++k) {
+                    const double gv = Wm[j * LD + k];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + r;
+                        if (k <= i) term(r, (k == i) ? dg[r] : Wm[row[r] + k], gv);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + r;
+                    if (i < M && j <= i) Rg[i * M + j] = s[r] + c[r];
+                }
             }
         }
         __syncthreads();
-        // correction of G: C[j][k] = sum_{i=j..k} R[i][j] G[i][k]   (W + W R, transposed)
-        for (int idx = tid; idx < M * M; idx += PREP_NT) {
-            const int j = idx / M, k = idx - j * M;
-            if (k < j) continue;
-            double cs = 0.0;
-            for (int i = j; i <= k; ++i) cs += Rg[i * M + j] * Wm[i * LD + k];
-            if (k == j) cdiag[j] = cs; else Rg[j * M + k] = cs;
+        // correction of G: C[j][k] = sum_{i=j..k} R[i][j] G[i][k]   (W + W R, transposed), 16 x 16 tiles of the upper
+        // triangle on the f64 MFMA units: A[row j][k = i] = R[i][j] (zero for i < j), B[k = i][col k] = G[i][k] (zero for k < i)
+        // (R sits in the lower triangle of the scratch incl. its diagonal, the correction goes to the strict upper triangle and
+        //  `cdiag`: the tiles are written as they are finished)
+        {
+            int cnt = 0;
+            for (int jb = 0; jb < NBT; ++jb) {
+                for (int kb = jb; kb < NBT; ++kb, ++cnt) {
+                    if ((cnt % NWAVE) != wv) continue;
+                    d4 acc = {0, 0, 0, 0};
+                    const int ja = 16 * jb + nl, kc = 16 * kb + nl;
+                    for (int ib = jb; ib <= kb; ++ib) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int i = 16 * ib + 4 * s4 + g;
+                            const double av = (ja < M && i < M && i >= ja) ? Rg[i * M + ja] : 0.0;
+                            const double bv = (kc < M && i < M && kc >= i) ? Wm[i * LD + kc] : 0.0;
+                            acc = CBF_MFMA(av, bv, acc);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * jb + g + 4 * r, k = 16 * kb + nl;
+                        if (j < M && k < M && k >= j) {
+                            if (k == j) cdiag[j] = acc[r]; else Rg[j * M + k] = acc[r];
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
         for (int idx = tid; idx < M * M; idx += PREP_NT) {
@@ -848,6 +910,7 @@ static int fill_prep(PrepArgs& a, const cbfssm_pack_layout* L, const double* Z, 
     a.invl = pack + L->invl; a.scal = pack + L->scal;
     a.muB = pack + L->muB; a.s2B = pack + L->s2B; a.ZT = pack + L->ZT; a.JB = L->JB;
     a.Wp = pack + L->Wp; a.WTp = pack + L->WTp;
+    a.refine_cond = refine_threshold();
     return 0;
 }
 
