@@ -9,8 +9,11 @@ reference training/trainer.py:46) and, for mode=train, the adjoint pass + Adam u
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank holds the same per-GPU workload
 (weak scaling: the global batch is N x B sequences) and the ranks exchange ONE all-reduce per step.  The default
-workload is C3 (Sarcos M=100, the config the metric is quoted on) at N=1 and C4 (Sarcos M=200, 256 sequences per GPU =
-BASELINE.json's 8-GPU config) at N>1; --workload overrides.
+workload is C3 (Sarcos M=100, the config the metric is quoted on) AT EVERY N, so that a 1 -> 2 -> 4 -> 8 series of
+`value` is one workload; --workload overrides.  A line printed at N>1 carries its own baseline: `single_rank` = the
+same steps on the same ranks in the same run with the collective off, `scaling_efficiency` = value / (N x that), and
+`eight_gpu_config` = the same pair of measurements for C4 (Sarcos M=200, 256 sequences per GPU = BASELINE.json's
+8-GPU config).
 """
 import argparse
 import json
@@ -65,13 +68,14 @@ def cpu_baseline(w, mode='eval', policy='auto'):
     Two thread settings: the reference's own session config (5 intra-op / 10 inter-op threads, training/trainer.py:22-26)
     and all cores the job may use.
 
-    policy 'auto' (default): samples at T = 8 and T = 64 first (they are the warm-ups and show how the time per GP call
-    converges); when the T = 64 sample predicts at most CBFSSM_CPU_FULL_LIMIT (90) seconds per full step the FULL-T step is
-    timed -- median of three on all cores, once with the reference session config -- and `extrapolated` is false (C3:
-    about a minute of CPU work in all; the autograd state of a full C3 train step is about 30 GB of host memory).
-    Otherwise a T = 128 sample is added and the largest sample is scaled linearly in the number of GP calls.
-    'sample': the T = 64 sample only, scaled.  'full': full T whatever it costs, median of five after two warm-ups
-    (BASELINE.md section 2).  mode=train times loss + reverse-mode gradient (what minimize() executes)."""
+    policy 'auto' (default): samples at T = 8 and T = 64 first (they show how the time per GP call converges); when the
+    T = 64 sample predicts at most CBFSSM_CPU_FULL_LIMIT (90) seconds per full step the FULL-T step is timed and
+    `extrapolated` is false -- with BASELINE.md section 2's statistic, the median of five after two warm-ups, when seven
+    full steps fit CBFSSM_CPU_BUDGET (240) seconds (C3: 7 x 18 s on 16 cores + one step with the reference session
+    config), the median of three otherwise (the autograd state of a full C3 train step is about 30 GB of host memory).
+    Above the limit a T = 128 sample is added and the largest sample is scaled linearly in the number of GP calls.
+    'sample': the T = 64 sample only, scaled.  'full': full T whatever it costs, median of five after two warm-ups.
+    mode=train times loss + reverse-mode gradient (what minimize() executes)."""
     from cbfssm import synthetic as syn
     from oracle import cbfssm_torch_ref as tref
     import dataclasses
@@ -114,7 +118,8 @@ def cpu_baseline(w, mode='eval', policy='auto'):
     limit = float(os.environ.get('CBFSSM_CPU_FULL_LIMIT', '90'))
     if policy == 'full' or (policy == 'auto' and predicted <= limit):
         T_s = w.T
-        if policy == 'full':
+        budget = float(os.environ.get('CBFSSM_CPU_BUDGET', '240'))
+        if policy == 'full' or 7.0 * predicted <= budget:
             reps_all, stat = 7, 'median of 5 after 2 warm-ups'
             ts = timed(T_s, ncores, reps_all)[2:]
         else:
@@ -156,8 +161,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default=None,
-                    help='C1..C5 (default: C3 on one GPU -- the config the metric is quoted on; C4, the 8-GPU '
-                         'config of BASELINE.json, 256 sequences per GPU, when --gpus > 1)')
+                    help='C1..C5 (default: C3 -- the config the metric is quoted on -- at every N; at N > 1 the line also '
+                         'carries C4, the 8-GPU config of BASELINE.json, 256 sequences per GPU, as `eight_gpu_config`)')
     ap.add_argument('--mode', default='auto', choices=['auto', 'eval', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'sample', 'full'])
@@ -193,8 +198,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
-    if args.workload is None:
-        args.workload = 'C3' if args.gpus == 1 else 'C4'
+    default_workload = args.workload is None
+    if default_workload:
+        args.workload = 'C3'          # the same workload at every N: a 1 -> N series of `value` is one workload
     w = syn.WORKLOADS[args.workload]
     cfg = w.model_config()
     mode = args.mode
@@ -208,65 +214,104 @@ def main():
     if args.dtype == 'float32':
         assert world == 1, 'float32 arithmetic: measured on one GPU'
 
-    # ---- synthetic inputs, resident in HBM before the timed region
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    u = torch.randn(w.B, w.T, w.dim_u, dtype=torch.float64, device=dev, generator=g)
-    y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=dev, generator=g)
-    if args.params == 'trained':
-        p_np = syn.trained_like_params(w, ls_mult=64.0, zeta_mean=0.1)
-    else:
-        p_np = syn.make_params(w, seed=1)
-    params = {k: torch.tensor(v, device=dev) for k, v in p_np.items()}
-    N = w.N
-    # fresh noise every step (the reference draws it inside the graph); the draw for step k+1 runs on a side stream
-    # while step k computes
-    noise_pipe = ops.NoisePipeline(dev, g)
-
-    def draw_noise():
-        return noise_pipe.next(w.T, N)
-
-    red = torch.zeros(8, dtype=torch.float64, device=dev)
-    if mode == 'train':
-        # N > 1: the data-parallel step can replay two HIP graphs around the eager all-reduce (tests/test_distributed_gpu.py);
-        # at this workload the launches are hidden behind the kernels anyway, so the bench keeps plain launches there
-        # unless asked (CBFSSM_DP_GRAPH=1)
-        use_graph = None if world == 1 else (os.environ.get('CBFSSM_DP_GRAPH') == '1')
-        stepper = HipTrainStep(cfg, params, dev, dist if world > 1 else None, graph=use_graph, dtype=args.dtype)
-
-        def step():
-            return stepper.step(u, y, draw_noise(), condition=True)
-    else:
-        from cbfssm.hip.train import HipElboGrad
-        eng = HipElboGrad(cfg, dev, dist if world > 1 else None, require_adjoint=False, dtype=args.dtype)
-        out8 = torch.zeros(8, dtype=torch.float64, device=dev)
-
-        def step():
-            # what Trainer's test pass fetches (loss only); N>1: the three data terms are all-reduced inside
-            loss_t, _, ws = eng.forward(params, u, y, draw_noise(), condition=True)
-            out8.copy_(ws.out)
-            out8[6] = loss_t
-            return out8
-
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    dt = time.perf_counter() - t0
+    def build(w, cfg):
+        """synthetic inputs of workload `w`, resident in HBM before the timed region, and its step: `step()` as the job
+        runs it (N > 1: with the step's one all-reduce), `step_local()` the same launches on this rank alone"""
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        u = torch.randn(w.B, w.T, w.dim_u, dtype=torch.float64, device=dev, generator=g)
+        y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=dev, generator=g)
+        if args.params == 'trained':
+            p_np = syn.trained_like_params(w, ls_mult=64.0, zeta_mean=0.1)
+        else:
+            p_np = syn.make_params(w, seed=1)
+        params = {k: torch.tensor(v, device=dev) for k, v in p_np.items()}
+        # fresh noise every step (the reference draws it inside the graph); the draw for step k+1 runs on a side stream
+        # while step k computes
+        noise_pipe = ops.NoisePipeline(dev, g)
+
+        def draw_noise():
+            return noise_pipe.next(w.T, w.N)
+
+        b = dict(w=w, cfg=cfg, u=u, y=y, params=params, draw_noise=draw_noise, stepper=None)
+        if mode == 'train':
+            # N > 1: the data-parallel step can replay two HIP graphs around the eager all-reduce
+            # (tests/test_distributed_gpu.py); at this workload the launches are hidden behind the kernels anyway, so the
+            # bench keeps plain launches there unless asked (CBFSSM_DP_GRAPH=1)
+            use_graph = None if world == 1 else (os.environ.get('CBFSSM_DP_GRAPH') == '1')
+            stepper = HipTrainStep(cfg, params, dev, dist if world > 1 else None, graph=use_graph, dtype=args.dtype)
+            b['stepper'] = stepper
+            b['step'] = lambda: stepper.step(u, y, draw_noise(), condition=True)
+            b['step_local'] = lambda: stepper.step(u, y, draw_noise(), condition=True, local=True)
+        else:
+            from cbfssm.hip.train import HipElboGrad
+            eng = HipElboGrad(cfg, dev, dist if world > 1 else None, require_adjoint=False, dtype=args.dtype)
+            out8 = torch.zeros(8, dtype=torch.float64, device=dev)
+
+            def step(local=False):
+                # what Trainer's test pass fetches (loss only); N>1: the three data terms are all-reduced inside
+                loss_t, _, ws = eng.forward(params, u, y, draw_noise(), condition=True, local=local)
+                out8.copy_(ws.out)
+                out8[6] = loss_t
+                return out8
+            b['step'] = step
+            b['step_local'] = lambda: step(local=True)
+        return b
+
+    def timed(stepfn, steps, warmup):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks"""
+        out = None
+        for _ in range(warmup):
+            out = stepfn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = stepfn()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        loss = float(out[6]) if mode == 'eval' else float(out)
+        assert np.isfinite(loss), 'non-finite loss'
+        return dt, loss
+
+    def with_baseline(b, steps, warmup):
+        """N > 1: the single-rank baseline of the SAME workload in the SAME run -- the same launches on every rank with the
+        collective off (each rank evaluates its own mini-batch as a single device would; max over ranks like `value`)"""
+        dt1, _ = timed(b['step_local'], steps, max(1, min(warmup, 2)))
+        return {'ms_per_step': dt1 / steps * 1e3, 'steps_per_s': steps / dt1, 'steps': steps,
+                'how': 'the same step on every rank with the all-reduce off, same process, right after the timed region'}
+
+    bld = build(w, cfg)
+    u, y, params, draw_noise, stepper = bld['u'], bld['y'], bld['params'], bld['draw_noise'], bld['stepper']
+    N = w.N
+    dt, loss = timed(bld['step'], args.steps, args.warmup)
+    single = eff = c4 = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    loss = float(out[6]) if mode == 'eval' else float(out)
-    assert np.isfinite(loss), 'non-finite loss'
+        single = with_baseline(bld, args.steps, args.warmup)
+        eff = (args.steps / dt) / single['steps_per_s']
+        if default_workload and mode == 'train' and not os.environ.get('CBFSSM_BENCH_NO_C4'):
+            # BASELINE.json's 8-GPU config (Sarcos M = 200, 256 sequences per GPU) beside the headline workload, with its
+            # own single-rank baseline: one SCALE record holds both
+            w4 = syn.WORKLOADS['C4']
+            k4 = max(3, min(args.steps, 10))
+            b4 = build(w4, w4.model_config())
+            dt4, loss4 = timed(b4['step'], k4, 2)
+            s4 = with_baseline(b4, k4, 2)
+            c4 = {'workload': '%s %s step: M=%d T=%d B=%d/GPU S=%d' % (w4.name, mode, w4.M, w4.T, w4.B, w4.S),
+                  'value': k4 / dt4 * world, 'unit': 'steps/s', 'steps': k4, 'ms_per_step': dt4 / k4 * 1e3,
+                  'global_batch': w4.B * world, 'loss': loss4, 'single_rank': s4,
+                  'scaling_efficiency': (k4 / dt4) / s4['steps_per_s'],
+                  'collective_bytes': int(b4['stepper'].engine.red.numel()) * 8}
+            del b4
+            torch.cuda.empty_cache()
 
     # ---- the step's ONE collective, timed by itself on every rank (all ranks take part; rank 0 reports): HIP events on
     # the launch stream for RCCL, wall clock around a synchronised call for the gloo rehearsal
@@ -430,11 +475,23 @@ def main():
                                                 'forward_pass_adjoint': kern['forward_pass_adjoint'][1] * share / t_rf / 1e12}}
         # the HBM-bound kernel of the path: log-likelihood + predictive moments, one pass
         # over the filtered trajectories.  Algorithmic bytes: x and y read once, the four (B,T,.) outputs written once.
+        # Timed on a ROTATION of trajectory buffers larger than the 256 MB Infinity Cache (a back-to-back loop over one
+        # 143 MB buffer is served from that cache and reads as 5 TB/s; in the step the kernel follows 7 GB of tile traffic
+        # and sees HBM): every call reads a buffer that has been evicted since its last use.
+        x_bytes = ws.x.numel() * 8
+        n_rot = max(2, int(3 * 256 * 2 ** 20 // max(x_bytes, 1)) + 1) if x_bytes < 3 * 256 * 2 ** 20 else 1
+        n_rot = min(n_rot, 64)
+        x_rot = [ws.x] + [ws.x.clone() for _ in range(n_rot - 1)]
+        ll_calls = [0]
+
         def k_ll():
-            lib.check(l.cbfssm_loglik_moments_f64(C.byref(prob), ops._ptr(var_y), ops._ptr(y), ops._ptr(ws.x),
+            xb = x_rot[ll_calls[0] % n_rot]
+            ll_calls[0] += 1
+            lib.check(l.cbfssm_loglik_moments_f64(C.byref(prob), ops._ptr(var_y), ops._ptr(y), ops._ptr(xb),
                                                   ops._ptr(ws.ll_part), ops._ptr(ws.pred_mean), ops._ptr(ws.pred_var),
                                                   ops._ptr(ws.int_mean), ops._ptr(ws.int_var), st), 'loglik')
-        t_ll = time_kernel(k_ll, 20)
+        t_ll = time_kernel(k_ll, max(20, 2 * n_rot))
+        del x_rot
         ll_bytes = 8.0 * (w.T * N * w.dim_x + w.B * w.T * (3 * w.dim_y + 2 * w.dim_x) + ws.ll_part.numel())
         name = max(kern, key=lambda k: kern[k][0])
         tk, fl = kern[name]
@@ -466,7 +523,10 @@ def main():
                             'outer product runs in cbfssm_stash_contract_f64 and is priced there (2 M^2 flops per GP point)'},
                 'hbm_kernel': {'kernel': 'loglik_moments', 'bound': 'hbm', 'ms': t_ll * 1e3,
                                'achieved': ll_bytes / t_ll / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': ll_bytes / t_ll / 1e9 / HBM_PEAK_GBS},
+                               'frac': ll_bytes / t_ll / 1e9 / HBM_PEAK_GBS,
+                               'timing': 'HIP events over calls that rotate through %d trajectory buffers (%.0f MB in all: '
+                                         'larger than the 256 MB Infinity Cache, so every read comes from HBM)'
+                                         % (n_rot, n_rot * x_bytes / 1e6)},
                 'hbm_algorithmic_GBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9,
                 'hbm_frac_of_8TBs': w.bytes_per_state() * w.B * w.T / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
 
@@ -484,6 +544,9 @@ def main():
                        'mode': mode, 'global_batch': w.B * world, 'seq_len': w.T, 'particles': w.S,
                        'parallelism': 'dp%d' % world},
             'loss': loss,
+            'single_rank': single,
+            'scaling_efficiency': eff,
+            'eight_gpu_config': c4,
             'collective': coll,
             'params': args.params,
             'roofline': roof,

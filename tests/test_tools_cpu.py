@@ -22,9 +22,12 @@ def test_cpu_baseline_times_the_full_step_when_it_is_affordable(monkeypatch):
         assert c['kind'] == 'port' and c['unit'] == 'steps/s' and c['value'] > 0 and c['cores'] >= 1
         assert c['extrapolated'] is False and c['sample_T'] == w.T and c['sample_gp_calls'] == 3 * w.T - 1
         assert set(c['seconds_per_gp_call_all_cores']) == {'T8', 'T20'}
-        assert 'median of 3' in c['statistic']
+        assert c['statistic'] == 'median of 5 after 2 warm-ups'          # BASELINE.md section 2, when seven steps are affordable
         assert c['value'] == 1.0 / min(c['threads']['all_cores']['seconds_per_step'],
                                        c['threads']['reference_session_config']['seconds_per_step'])
+    # seven full steps do not fit the budget: the median of three
+    monkeypatch.setenv('CBFSSM_CPU_BUDGET', '0')
+    assert 'median of 3' in bench.cpu_baseline(w, 'eval', policy='auto')['statistic']
     # an unaffordable full step: a T = 128 sample, scaled linearly in the number of GP calls
     monkeypatch.setenv('CBFSSM_CPU_FULL_LIMIT', '0')
     w2 = syn.tiny(M=12, T=200, B=1, S=2)
