@@ -152,7 +152,11 @@ constexpr bool rev_extra_wave(int, bool) { return false; }
 // tile in LDS -- the row-block waves shed 32 accumulator VGPRs (spill slots 64 -> 48 / 34 -> 12) and 16 MFMAs per step, the
 // kernels did not move: 9.68 / 13.35 ms.  And kernel tiles kept by the forward evaluation for these tile heights, read back
 // instead of rebuilt: 10.9 / 15.9 ms loaded at the step top, 11.1 / 15.9 ms prefetched a step ahead -- slower both ways.)
+#ifdef CBF_REV_RB13
+constexpr bool rev_extra_wave(int nblk, bool stash) { return stash ? (nblk != 16 && nblk != 13) : (nblk == 7); }
+#else
 constexpr bool rev_extra_wave(int nblk, bool stash) { return stash ? (nblk != 16) : (nblk == 7); }
+#endif
 #endif
 
 // KD: k-steps of the products whose k index is the GP output dimension (mu Fm, s2 Fv): 4 in general, 2 when the launcher

@@ -12,7 +12,11 @@ namespace cbfssm {
 template <int NBLK>
 struct RevCfg {
     static constexpr bool STASH = (NBLK > 7);
+#ifdef CBF_REV_RB13      // diagnostic builds: row blocks per wave at 13 row blocks (4: four waves, one per SIMD, up to 512 registers)
+    static constexpr int RB = (NBLK == 13) ? CBF_REV_RB13 : (STASH ? 2 : 1);
+#else
     static constexpr int RB = STASH ? 2 : 1;
+#endif
     static constexpr int W = (NBLK + RB - 1) / RB;
 };
 

@@ -89,3 +89,18 @@ def test_traffic_json_sums_the_stash_mode_launches_per_step(tmp_path):
     assert d['backward_pass_adjoint'] == int((2.0 * 300.0 + 30.0) * kib)        # 6 launches / 2 steps = 3 per step
     assert d['stash_contraction'] == int((2.0 * 100.0 + 10.0) * kib)
     assert d['backward_pass'] == int((2.0 * 40.0 + 4.0) * kib)                  # the largest dispatch
+
+
+def test_two_rank_bench_line_carries_its_own_baseline():
+    """The N > 1 line of bench.py (the committed two-rank rehearsal on one device): the same workload as N = 1, the
+    single-rank step time of that workload measured in the same run, the efficiency that follows, the 8-GPU config (C4)
+    with its own baseline, and the collective with its rank count."""
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r04', 'bench_2ranks_one_device.json')).read().strip().splitlines()[-1])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['workload'].startswith('C3-Sarcos')
+    assert set(d['single_rank']) >= {'ms_per_step', 'steps_per_s', 'steps', 'how'}
+    assert np.isclose(d['scaling_efficiency'], d['value'] / (d['n_gpus'] * d['single_rank']['steps_per_s']), rtol=1e-9)
+    c4 = d['eight_gpu_config']
+    assert c4['workload'].startswith('C4-Sarcos-M200') and c4['global_batch'] == 2 * 256
+    assert set(c4) >= {'value', 'ms_per_step', 'single_rank', 'scaling_efficiency', 'collective_bytes'}
+    assert np.isclose(c4['scaling_efficiency'], c4['value'] / (d['n_gpus'] * c4['single_rank']['steps_per_s']), rtol=1e-9)
+    assert d['collective']['ranks'] == 2 and d['collective']['per_step'] == 1 and d['collective']['sum_checked'] is True
