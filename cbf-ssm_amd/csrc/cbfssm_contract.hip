@@ -181,6 +181,186 @@ __global__ __launch_bounds__(64 * ((NBLK + 1) / 2)) void stash_contract2_kernel(
     }
 }
 
+// Third form: only the SYMMETRIC PART of the sum is ever used -- the train tail maps d loss / d K^-1 to d loss / d K_mm =
+// -K^-1 (.) K^-1 and every consumer contracts that with a symmetric dK_mm/dtheta (cbfssm_tail.hip, cbfssm.py:273-275 through
+// gp_tf.py:129-130) -- so this form accumulates the lower-triangular 16 x 16 blocks of  S = sum (A2bar K^T + K A2bar^T)  only:
+// NBLK (NBLK + 1) / 2 accumulator tiles instead of NBLK^2 (91 instead of 169 at NBLK = 13, 210 instead of 400 at 20) for the
+// same number of MFMAs (eight per off-diagonal block: both images have the SAME lane layout, X[m = lane & 15][n = 4 s +
+// (lane >> 4)], which is at once the A operand of X and the B operand of X^T, so  S_ij += A_i K_j^T + K_i A_j^T  is two
+// MFMAs per k-step on one accumulator; the diagonal blocks take A_i K_i^T only and are symmetrised by the reduction).
+// What the halved accumulator buys: ONE workgroup holds the whole triangle at every tile height (so each slot's two images
+// are read from HBM exactly once -- the row-group form above reads the K^T image once per row group), and ANY wave can take
+// ANY block (all operands are in LDS), so the blocks are dealt to the waves by MFMA count: every SIMD issues the same
+// number -- the two-row-blocks-per-wave form loads the four SIMDs 4-4-3-2 at 13 row blocks (its own bound: 5.2 ms of the C4
+// step against 4.2 ms here).
+constexpr int tri_row(int b) { int i = 0; while ((i + 1) * (i + 2) / 2 <= b) ++i; return i; }
+constexpr int tri_col(int b) { return b - tri_row(b) * (tri_row(b) + 1) / 2; }
+constexpr int sym_waves(int) { return 8; }
+// workgroups per slot slice: one holds the whole triangle up to 16 row blocks (17 accumulator tiles per wave); at 20 the 210
+// tiles go to two workgroups of eight waves (13-14 tiles each: 27 per wave would spill), the first of which needs -- and
+// stages -- only the image rows of its own block rows
+constexpr int sym_groups(int nblk) { return nblk >= 20 ? 2 : 1; }
+template <int NBLK, int NW>
+constexpr int sym_start(int w)                   // first block of wave w: the blocks in row-major order, cut at equal MFMA counts
+{
+    constexpr int NB = NBLK * (NBLK + 1) / 2, TOT = NBLK * NBLK;
+    if (w >= NW) return NB;
+    int b = 0, i = 0, j = 0, wsum = 0;              // wsum: MFMAs / 4 of the blocks [0, b): two per off-diagonal block, one per diagonal one
+    while (b < NB && wsum * NW < TOT * w) {
+        wsum += (i == j) ? 1 : 2;
+        ++b;
+        if (j == i) { ++i; j = 0; } else ++j;
+    }
+    return b;
+}
+template <int NBLK, int NW>
+constexpr int sym_maxcount()
+{
+    int m = 0;
+    for (int w = 0; w < NW; ++w) {
+        const int c = sym_start<NBLK, NW>(w + 1) - sym_start<NBLK, NW>(w);
+        if (c > m) m = c;
+    }
+    return m;
+}
+
+// blocks [B, END) of one wave, two at a time where they share a row (their MFMAs alternate between two accumulators)
+template <int NBLK, int START, int END, int B, int MAXC>
+__device__ __forceinline__ void sym_blocks(d4 (&acc)[MAXC], const double* Al, const double* Kl, double (&ra)[4], double (&rk)[4])
+{
+    if constexpr (B < END) {
+        constexpr int i = tri_row(B), j = tri_col(B);
+        if constexpr (B == START || tri_row(B - 1) != i) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { ra[s] = Al[(i * 4 + s) * 64]; rk[s] = Kl[(i * 4 + s) * 64]; }
+        }
+        constexpr bool PAIR = (B + 1 < END) && (tri_row(B + 1) == i);
+        if constexpr (PAIR) {
+            constexpr int j1 = j + 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double k0 = Kl[(j * 4 + s) * 64], k1 = Kl[(j1 * 4 + s) * 64];
+                acc[B - START] = CBF_MFMA(ra[s], k0, acc[B - START]);
+                acc[B + 1 - START] = CBF_MFMA(ra[s], k1, acc[B + 1 - START]);
+                const double a0 = Al[(j * 4 + s) * 64];
+                acc[B - START] = CBF_MFMA(rk[s], a0, acc[B - START]);                      // (j < j1 <= i: off the diagonal)
+                if constexpr (j1 != i) {
+                    const double a1 = Al[(j1 * 4 + s) * 64];
+                    acc[B + 1 - START] = CBF_MFMA(rk[s], a1, acc[B + 1 - START]);
+                }
+            }
+            sym_blocks<NBLK, START, END, B + 2, MAXC>(acc, Al, Kl, ra, rk);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double k0 = Kl[(j * 4 + s) * 64];
+                acc[B - START] = CBF_MFMA(ra[s], k0, acc[B - START]);
+                if constexpr (j != i) {
+                    const double a0 = Al[(j * 4 + s) * 64];
+                    acc[B - START] = CBF_MFMA(rk[s], a0, acc[B - START]);
+                }
+            }
+            sym_blocks<NBLK, START, END, B + 1, MAXC>(acc, Al, Kl, ra, rk);
+        }
+    }
+}
+
+// One wave's whole pass: its own accumulator array (statically indexed: it stays in registers), the slot loop, the store.
+// NW: waves of a workgroup, NV = NW x groups: virtual waves the triangle is dealt to, WV: this wave's index among them.
+template <int NBLK, int NW, int NV, int WV>
+__device__ __forceinline__ void sym_run(const double* __restrict__ sa, const double* __restrict__ sk, int64_t s_begin, int64_t s_end,
+                                        double* lds, int l, double* __restrict__ o)
+{
+    constexpr int S0 = sym_start<NBLK, NV>(WV), S1 = sym_start<NBLK, NV>(WV + 1), CNT = S1 - S0;
+    constexpr int IMG = NBLK * 256;                     // doubles of one operand image (one slot)
+    constexpr int PIMG = IMG / 128;                     // 1-KiB pieces per image (two per row block)
+    constexpr int GRP = WV / NW;                        // this wave's workgroup among the groups of a slice
+    constexpr int ROWS = tri_row(sym_start<NBLK, NV>((GRP + 1) * NW) - 1) + 1;     // image row blocks this workgroup reads
+    constexpr int PROW = 2 * ROWS;                      // ... = pieces of each image it stages
+    d4 acc[CNT > 0 ? CNT : 1];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) acc[k] = d4{0, 0, 0, 0};
+
+    auto stage = [&](int64_t slot, int buf) {
+        double* dst = lds + buf * 2 * IMG;
+#pragma unroll
+        for (int k = 0; k < (2 * PROW + NW - 1) / NW; ++k) {
+            const int q = (WV % NW) + k * NW;           // piece of this wave: A image pieces first, then the K image
+            if (q < 2 * PROW) {
+                const int p = (q < PROW) ? q : PIMG + (q - PROW);
+                const double* src = (q < PROW) ? sa + slot * IMG + q * 128 : sk + slot * IMG + (q - PROW) * 128;
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(src + 2 * l), (lds_void_t*)(dst + p * 128), 16, 0, 0);
+            }
+        }
+    };
+
+    if (s_begin < s_end) {
+        stage(s_begin, 0);
+        __syncthreads();                                 // (its fence waits for the LDS-DMA: vmcnt(0))
+        for (int64_t slot = s_begin; slot < s_end; ++slot) {
+            const int buf = int(slot - s_begin) & 1;
+            if (slot + 1 < s_end) stage(slot + 1, buf ^ 1);       // read last in the previous iteration, before its barrier
+            const double* Al = lds + buf * 2 * IMG + l;
+            double ra[4], rk[4];
+            sym_blocks<NBLK, S0, S1, S0, (CNT > 0 ? CNT : 1)>(acc, Al, Al + IMG, ra, rk);
+            __syncthreads();                             // next slot's images landed (vmcnt(0)), this buffer free
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CNT; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(S0 + k) * 256 + r * 64 + l] = acc[k][r];
+}
+
+template <int NBLK, int NW, int NV, int WV>
+__device__ __forceinline__ void sym_dispatch(int gw, const double* sa, const double* sk, int64_t s_begin, int64_t s_end, double* lds,
+                                             int l, double* o)
+{
+    if constexpr (WV < NV) {
+        if (gw == WV) sym_run<NBLK, NW, NV, WV>(sa, sk, s_begin, s_end, lds, l, o);    // (gw is wave-uniform: a scalar branch)
+        else sym_dispatch<NBLK, NW, NV, WV + 1>(gw, sa, sk, s_begin, s_end, lds, l, o);
+    }
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(64 * sym_waves(NBLK)) void stash_contract_sym_kernel(const double* __restrict__ sa,
+                                                                                   const double* __restrict__ sk, int64_t nslots,
+                                                                                   int64_t slots_per_wg, double* __restrict__ part)
+{
+    constexpr int NW = sym_waves(NBLK), NV = NW * sym_groups(NBLK);
+    constexpr int NB = NBLK * (NBLK + 1) / 2;
+    extern __shared__ double lds[];                     // [2][A image | K image]
+    const int tid = threadIdx.x, l = tid & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(int(blockIdx.y) * NW + (tid >> 6));
+    const int64_t s_begin = int64_t(blockIdx.x) * slots_per_wg;
+    const int64_t s_end = (s_begin + slots_per_wg < nslots) ? s_begin + slots_per_wg : nslots;
+    // every wave of a workgroup runs the same slot loop with the same two barriers per slot, each on its own blocks
+    sym_dispatch<NBLK, NW, NV, 0>(gw, sa, sk, s_begin, s_end, lds, l, part + int64_t(blockIdx.x) * NB * 256);
+}
+
+// out (the full [NBLK][NBLK] C-layout image) += the symmetric part of the sum: (S + S^T) / 2 with S the lower-triangular
+// partial images, summed over the slices in a fixed order.  C layout of a block: row = (lane >> 4) + 4 reg, column = lane & 15.
+__global__ void contract_reduce_sym_kernel(const double* part, int nblk, int nsplit, double* out)
+{
+    const int64_t n = int64_t(nblk) * nblk * 256, nb256 = int64_t(nblk) * (nblk + 1) / 2 * 256;
+    const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int e = int(idx & 255), blk = int(idx >> 8), I = blk / nblk, J = blk % nblk;
+    const int rr = ((e & 63) >> 4) + 4 * (e >> 6), cc = e & 15;
+    const int eT = (cc >> 2) * 64 + (cc & 3) * 16 + rr;             // the element (cc, rr) of a block
+    const int hi = I > J ? I : J, lo = I > J ? J : I;
+    const int64_t b = (int64_t(hi) * (hi + 1) / 2 + lo) * 256;
+    double s = 0.0;
+    if (I > J) {
+        for (int k = 0; k < nsplit; ++k) s += part[k * nb256 + b + e];
+    } else if (I < J) {
+        for (int k = 0; k < nsplit; ++k) s += part[k * nb256 + b + eT];
+    } else {
+        for (int k = 0; k < nsplit; ++k) s += part[k * nb256 + b + e] + part[k * nb256 + b + eT];
+    }
+    out[idx] += 0.5 * s;
+}
+
 // out[i] += sum_k part[k][i] in a fixed order
 __global__ void contract_reduce_kernel(const double* part, int64_t n, int nsplit, double* out)
 {
@@ -215,6 +395,18 @@ static int launch_contract(const double* sa, const double* sk, int64_t nslots, d
     const int64_t per = (nslots + nsplit - 1) / nsplit;
     constexpr int CONTRACT_WAVES = contract_waves(NBLK);
     const int nrg = (NBLK + CONTRACT_WAVES - 1) / CONTRACT_WAVES;
+    if (!getenv("CBFSSM_CONTRACT_FULL")) {              // (measurement switch: the full-matrix forms below)
+        const size_t lds3 = size_t(4) * NBLK * 256 * sizeof(double);
+        auto k3 = stash_contract_sym_kernel<NBLK>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds3));
+        if (e != hipSuccess) return -int(e) - 1000;
+        hipLaunchKernelGGL(k3, dim3(unsigned(nsplit), unsigned(sym_groups(NBLK))), dim3(64 * sym_waves(NBLK)), lds3, st, sa, sk, nslots, per, work);
+        const int64_t n3 = int64_t(NBLK) * NBLK * 256;
+        hipLaunchKernelGGL(contract_reduce_sym_kernel, dim3(unsigned((n3 + 255) / 256)), dim3(256), 0, st, (const double*)work,
+                           NBLK, nsplit, out);
+        e = hipGetLastError();
+        return e == hipSuccess ? 0 : -int(e) - 1000;
+    }
     if constexpr (NBLK <= 13) {
         if (!getenv("CBFSSM_CONTRACT_V1")) {            // (measurement switch: the row-group form)
             const size_t lds2 = size_t(4) * NBLK * 256 * sizeof(double);

@@ -9,10 +9,14 @@
 //
 // Same step structure as rev_kernel (phases B, C, E, F, G, D between four workgroup barriers), written once for every
 // tile height, nothing kept by the forward evaluation except (fmean, fvar) and the trajectories: the kernel tile and A2
-// are recomputed.  The accumulator of the K_mm adjoint's data part (NBLK^2 tiles of 4 VGPRs; see phase F: it holds
-// (K^-1 A2bar) A2^T, not A2bar K^T) stays in registers for the whole pass; above 13
-// row blocks a launch accumulates NCB of the NBLK column blocks and the host launches ceil(NBLK / NCB) passes (the later
-// ones repeat the sweep and write only their columns).  This is the path of a reduced-precision model, not the headline.
+// are recomputed.  The accumulator of the K_mm adjoint's data part (tiles of 4 VGPRs; see phase F: it holds
+// (K^-1 A2bar) A2^T, not A2bar K^T) stays in registers for the whole pass.  One row block per wave (up to 10 row blocks): the
+// wave's NBLK tiles of the full matrix.  Two row blocks per wave (13, 16, 20 row blocks; SYMG): only the SYMMETRIC part of
+// that matrix is ever used (it is d loss / d K_mm, contracted with symmetric dK_mm/dtheta), so the waves accumulate the
+// lower-triangular blocks of  S = C A2^T + A2 C^T,  C = K^-1 A2bar  -- NBLK (NBLK + 1) / 2 tiles, dealt so that wave w owns
+// the block rows w and NBLK - 1 - w (NBLK + 1 tiles each: 84 VGPRs at 20 row blocks) -- in ONE pass over the time loop.
+// (Round 3 held NBLK / 2 column blocks of the full matrix per pass and ran the time loop twice above 13 row blocks.)
+// This is the path of a reduced-precision model, not the headline.
 //
 // v_mfma_f32_16x16x4_f32: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
 // C[row = 4 (lane >> 4) + reg][col = lane & 15] -- register r of lane group g is row 4 g + r (the f64 instruction: 4 r + g).
@@ -51,6 +55,84 @@ struct Rev32Args {
     int group0, gtotal;    // chain-group split: this launch covers groups [group0, group0 + gridDim.x) of gtotal
 };
 
+// SYMG accumulation of one block row: S[row][j] += C_row A2_j^T + A2_row C_j^T for j = J..row, two blocks at a time (their
+// MFMAs alternate between two accumulators).  cT / aT: the row's C and A2 rows as A operands [m][k = chain]; the column
+// blocks' rows as B operands [k = chain][m] come from the same two LDS tiles (an A-operand image of X is the B-operand
+// image of X^T).  The diagonal block takes C A2^T only; the host symmetrises.
+template <int ROW, int J, int OFF, int NG>
+__device__ __forceinline__ void symg_row(f4 (&gS)[NG], const float (&cT)[4], const float (&aT)[4], const float* Ct, const float* A2k,
+                                         int g, int nl)
+{
+    constexpr int PD = 17;
+    if constexpr (J <= ROW) {
+        if constexpr (J + 1 <= ROW) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float a0 = A2k[(16 * J + nl) * PD + 4 * s + g], a1 = A2k[(16 * (J + 1) + nl) * PD + 4 * s + g];
+                gS[OFF + J] = CBF_MFMA32(cT[s], a0, gS[OFF + J]);
+                gS[OFF + J + 1] = CBF_MFMA32(cT[s], a1, gS[OFF + J + 1]);
+                const float c0 = Ct[(16 * J + nl) * PD + 4 * s + g];
+                gS[OFF + J] = CBF_MFMA32(aT[s], c0, gS[OFF + J]);
+                if constexpr (J + 1 < ROW) {
+                    const float c1 = Ct[(16 * (J + 1) + nl) * PD + 4 * s + g];
+                    gS[OFF + J + 1] = CBF_MFMA32(aT[s], c1, gS[OFF + J + 1]);
+                }
+            }
+            symg_row<ROW, J + 2, OFF, NG>(gS, cT, aT, Ct, A2k, g, nl);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float a0 = A2k[(16 * J + nl) * PD + 4 * s + g];
+                gS[OFF + J] = CBF_MFMA32(cT[s], a0, gS[OFF + J]);                  // (J == ROW: the diagonal block)
+            }
+        }
+    }
+}
+
+// wave WID of a SYMG tile: block rows R1 = NBLK - 1 - WID (tiles gS[0 .. R1]) and R0 = WID < R1 (tiles gS[R1 + 1 .. NBLK])
+template <int NBLK, int WID>
+__device__ __forceinline__ void symg_accum(f4 (&gS)[NBLK + 1], const float* Ct, const float* A2k, int g, int nl)
+{
+    constexpr int PD = 17, R0 = WID, R1 = NBLK - 1 - WID;
+    float cT[4], aT[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { cT[s] = Ct[(16 * R1 + nl) * PD + 4 * s + g]; aT[s] = A2k[(16 * R1 + nl) * PD + 4 * s + g]; }
+    symg_row<R1, 0, 0, NBLK + 1>(gS, cT, aT, Ct, A2k, g, nl);
+    if constexpr (R1 > R0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { cT[s] = Ct[(16 * R0 + nl) * PD + 4 * s + g]; aT[s] = A2k[(16 * R0 + nl) * PD + 4 * s + g]; }
+        symg_row<R0, 0, R1 + 1, NBLK + 1>(gS, cT, aT, Ct, A2k, g, nl);
+    }
+}
+template <int NBLK, int WID>
+__device__ __forceinline__ void symg_store(const f4 (&gS)[NBLK + 1], double* gBslab, int img)
+{
+    constexpr int R0 = WID, R1 = NBLK - 1 - WID;
+#pragma unroll
+    for (int j = 0; j <= R1; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gBslab[(R1 * NBLK + j) * 256 + img + r * 16] = double(gS[j][r]);
+    if constexpr (R1 > R0) {
+#pragma unroll
+        for (int j = 0; j <= R0; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gBslab[(R0 * NBLK + j) * 256 + img + r * 16] = double(gS[R1 + 1 + j][r]);
+    }
+}
+template <int NBLK, int WID, bool STORE>
+__device__ __forceinline__ void symg_dispatch(int w, f4 (&gS)[NBLK + 1], const float* Ct, const float* A2k, int g, int nl,
+                                              double* gBslab, int img)
+{
+    if constexpr (WID < (NBLK + 1) / 2) {
+        if (w == WID) {                                    // (w is wave-uniform: a scalar branch)
+            if constexpr (STORE) symg_store<NBLK, WID>(gS, gBslab, img);
+            else symg_accum<NBLK, WID>(gS, Ct, A2k, g, nl);
+        } else {
+            symg_dispatch<NBLK, WID + 1, STORE>(w, gS, Ct, A2k, g, nl, gBslab, img);
+        }
+    }
+}
+
 // TRI: every product with K^-1 = W^T W (A2 = K^-1 K in phase C, K^-1 A2bar in phase F) runs as two triangular products
 // W (.) then W^T (.) with W = L^-1, the way the reference back-substitutes twice (gp_tf.py:137,145) -- the zero blocks are
 // skipped, the intermediate rows travel through one more LDS tile and one more workgroup barrier per product.  In float32
@@ -66,6 +148,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     constexpr int PD = 17;
     constexpr int PSL = (JB > 2 ? JB : 2) * 256;
     constexpr int AUXR = (DK * 64 + NT - 1) / NT;
+    constexpr bool SYMG = (RB == 2);                    // symmetric K_mm-adjoint accumulator, block rows (w, NBLK - 1 - w) per wave
+    static_assert(!SYMG || NCB == 1, "SYMG tiles accumulate the whole triangle in one pass");
     typedef Slab<NBLK, JB, false> SL;
 
     extern __shared__ float lds32r[];
@@ -78,8 +162,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     float* part = Fv + 16 * PD;                // [W][PSL]
     float* A2k = part + W * PSL;               // [MP][17]  A2 rows of every wave, kept from phase E for the accumulation in F
     float* At = A2k + MP * PD;                 // [MP][17]  (TRI: rows of W K / W A2bar between the two triangular products)
+    float* Ct = At + (TRI ? MP * PD : 0);      // [MP][17]  (SYMG: C = K^-1 A2bar rows of every wave, from phase F to barrier 6)
 
-    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, g = l >> 4, nl = l & 15;
+    const int tid = threadIdx.x, l = tid & 63, g = l >> 4, nl = l & 15;
+    const int w = SYMG ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int N = a.N, S = a.S, T = a.T, Do = a.Do, D = a.D;
     const int naux = D - Do;
     const int dob = a.dim_x - a.dim_y;
@@ -98,9 +184,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     int rbs[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        ok[i] = (w * RB + i) < NBLK;
-        rbs[i] = ok[i] ? (w * RB + i) : (NBLK - 1);
+        if constexpr (SYMG) {
+            const int rb = (i == 0) ? w : NBLK - 1 - w;            // (the middle wave of an odd NBLK owns one row block)
+            ok[i] = (i == 0) || (rb > w);
+            rbs[i] = ok[i] ? rb : (NBLK - 1);
+        } else {
+            ok[i] = (w * RB + i) < NBLK;
+            rbs[i] = ok[i] ? (w * RB + i) : (NBLK - 1);
+        }
     }
+    const int rb_lo = rbs[0], rb_hi = ok[RB - 1] ? rbs[RB - 1] : rbs[0];      // (two-triangular products: the k-block ranges)
     // Z~ rows and row constants of the owned row blocks (kernel tile, gp_tf.py:33-49)
     float Zreg[RB][DK], czr[RB][4];
 #pragma unroll
@@ -119,6 +212,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     }
 
     f4 gMu[RB], gS2[RB], gZ[RB][JB], gB[RB][NCB];
+    f4 gS[SYMG ? NBLK + 1 : 1];
+#pragma unroll
+    for (int k = 0; k < (SYMG ? NBLK + 1 : 1); ++k) gS[k] = f4{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         gMu[i] = f4{0, 0, 0, 0};
@@ -379,7 +475,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                             if (ok[i]) acc[i][j & 1] = CBF_MFMA32(aop[i][j], b[j], acc[i][j & 1]);
                 }
             } else {
-                const int rb_hi = rbs[RB - 1];                       // (a missing second row block repeats NBLK - 1: dropped)
 #pragma unroll 1
                 for (int kb = 0; kb <= rb_hi; ++kb) {                // W is lower triangular: k-blocks kb <= rb
                     float b[4], aop[RB][4];
@@ -405,7 +500,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                 }
                 __syncthreads();
 #pragma unroll 1
-                for (int kb = w * RB; kb < NBLK; ++kb) {             // W^T is upper triangular: k-blocks kb >= rb
+                for (int kb = rb_lo; kb < NBLK; ++kb) {              // W^T is upper triangular: k-blocks kb >= rb
                     float b[4], aop[RB][4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -489,6 +584,14 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
             // multiplies the float32 accumulator by K^-1 from both sides afterwards (that amplified its rounding by
             // cond(K_mm): 1.6e-3 on the gradient at cond 4e4).  The host hands K_mm' G K_mm' to the float64 tail, which
             // expects d loss / d K^-1.  Transposes through this wave's own rows of the K tile (dead after phase E).
+            if constexpr (SYMG) {
+                // C rows of this wave -> the C tile; the accumulation follows barrier 5 (every wave's rows are there then)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+                    if (ok[i])
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Ct[(16 * rbs[i] + 4 * g + r) * PD + nl] = kb_[i][r];
+            } else {
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 if (ok[i]) {
@@ -511,6 +614,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                         }
                     }
                 }
+            }
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -560,6 +664,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
             }
         }
         __syncthreads();                                                                           // 5
+        // SYMG: S += C A2^T + A2 C^T on this wave's block rows, both tiles complete and untouched until the next step's
+        // phase E / F -- in the shadow of phases G / D, which are vector latency on the first waves
+        if constexpr (SYMG) symg_dispatch<NBLK, 0, false>(w, gS, Ct, A2k, g, nl, nullptr, 0);
 
         // ---- G: input adjoint, carried to the next reverse step.  Lane (g, nl) of group gi = 4 jb + q holds input row
         // j = 16 jb + 4 g + q of chain nl (register q of the xbar tile)
@@ -645,12 +752,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
 #pragma unroll
                     for (int jb = 0; jb < JB; ++jb) slab[SL::gZ + (rb * JB + jb) * 256 + img + r * 16] = double(gZ[i][jb][r]);
                 }
+                if constexpr (!SYMG) {
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb)
-                    if (a.cb0 + cb < NBLK) slab[SL::gB + (rb * NBLK + a.cb0 + cb) * 256 + img + r * 16] = double(gB[i][cb][r]);
+                    for (int cb = 0; cb < NCB; ++cb)
+                        if (a.cb0 + cb < NBLK) slab[SL::gB + (rb * NBLK + a.cb0 + cb) * 256 + img + r * 16] = double(gB[i][cb][r]);
+                }
             }
         }
     }
+    // (SYMG: the lower-triangular blocks; the blocks above the diagonal of the slab section are never written and stay zero)
+    if constexpr (SYMG) symg_dispatch<NBLK, 0, true>(w, gS, nullptr, nullptr, g, nl, slab + SL::gB, img);
     if (!first) return;
     for (int i = tid; i < 192; i += NT) slab[SL::small + i] = 0.0;
     __syncthreads();
@@ -681,9 +792,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     }
 }
 
-// Kinvbar column blocks one launch accumulates: all of them up to 13 row blocks (two row blocks per wave: 104 accumulator
-// VGPRs), half of them above
-constexpr int rev32_ncb(int nblk) { return nblk <= 13 ? nblk : (nblk + 1) / 2; }
+// column blocks of the K_mm-adjoint accumulator one launch holds per row block: all of them (one pass over the time loop at
+// every tile height since the two-row-block tiles accumulate the symmetric part only)
+constexpr int rev32_ncb(int nblk) { return nblk; }
 
 template <int NBLK, int DK, bool TRI>
 static int launch_rev32(int mode, const Rev32Args& a, dim3 grid, hipStream_t st)
@@ -692,8 +803,8 @@ static int launch_rev32(int mode, const Rev32Args& a, dim3 grid, hipStream_t st)
     constexpr int W = (NBLK + RB - 1) / RB;
     constexpr int JB = (4 * DK + 1 + 15) / 16;
     constexpr int PSL = (JB > 2 ? JB : 2) * 256;
-    constexpr int NCB = rev32_ncb(NBLK);
-    const size_t lds = size_t(2 * 4 * DK * 17 + (TRI ? 4 : 3) * 16 * NBLK * 17 + 2 * 16 * 17 + W * PSL) * sizeof(float);
+    constexpr int NCB = (RB == 2) ? 1 : rev32_ncb(NBLK);        // (RB == 2: the symmetric accumulator, see the kernel)
+    const size_t lds = size_t(2 * 4 * DK * 17 + ((TRI ? 4 : 3) + (RB == 2 ? 1 : 0)) * 16 * NBLK * 17 + 2 * 16 * 17 + W * PSL) * sizeof(float);
     hipError_t e = hipSuccess;
     if (mode == MODE_FWD) {
         auto k = rev32_kernel<NBLK, RB, DK, MODE_FWD, NCB, TRI>;
