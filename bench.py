@@ -30,6 +30,8 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (spec); csrc/probe/mfma_f64_probe measures 77.7 on the box
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X FP32 matrix, v_mfma_f32_16x16x4_f32 at 32 cycles per SIMD (MI355X_MICROARCH.md: 155 measured;
+                              # csrc/probe/mfma_f64_probe prints the rate it measures on the box)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -155,6 +157,92 @@ def cpu_baseline(w, mode='eval', policy='auto'):
                          ' + reverse-mode autodiff' if mode == 'train' else '')}
 
 
+def bench_variant(args, dev):
+    """ELBO-step throughput of the forward-only variants: CBFSSMHALF
+    (cbfssm/model/cbfssmhalf.py:117-196) and the PR-SSM baseline (cbfssm/model/prssm.py:96,117-118) on a BASELINE workload
+    shape.  A step = recognition model, K_mm / Cholesky / K^-1 + packing, the forward pass, log-likelihood + moments, and for
+    mode=train the adjoint pass, the K_mm adjoint + prior KL and the TF-1.8 Adam update."""
+    from cbfssm import synthetic as syn
+    from cbfssm.hip.train_half import HipHalfGrad
+    from cbfssm.hip.train import TFAdam
+    from cbfssm.hip import ops
+    w = syn.WORKLOADS[args.workload or 'C3']
+    mode = 'train' if args.mode == 'auto' else args.mode
+    cfg, p_np = syn.make_variant_params(w, args.model, 'rnn')
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    u = torch.randn(w.B, w.T, w.dim_u, dtype=torch.float64, device=dev, generator=g)
+    y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=dev, generator=g)
+    eng = HipHalfGrad(cfg, dev, variant=args.model)
+    opt = TFAdam({k: torch.tensor(v, device=dev) for k, v in p_np.items()}, cfg['learning_rate'])
+    params = opt.views
+    noise_pipe = ops.NoisePipeline(dev, g, with_backward=False)
+
+    def step():
+        noise = noise_pipe.next(w.T, w.N)
+        if mode == 'train':
+            loss, grads, _ = eng.loss_and_grads(params, u, y, noise, True)
+            opt.step(grads)
+            return loss
+        return eng.forward(params, u, y, noise, True)[0]
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = float(out)
+    assert np.isfinite(loss), 'non-finite loss'
+
+    # ---- the time-loop kernels by themselves: every launch of a step bracketed by HIP events (eng._prof)
+    ms, n = {}, {}
+    for _ in range(3):
+        eng._prof = []
+        step()
+        torch.cuda.synchronize()
+        ms, n = {}, {}
+        for kind, e0, e1 in eng._prof:
+            ms[kind] = ms.get(kind, 0.0) + e0.elapsed_time(e1)
+            n[kind] = n.get(kind, 0) + 1
+    eng._prof = None
+
+    def F(M, D, Do):   # SURVEY.md section 8(d): algorithmic FLOPs of one GP point evaluation
+        return 2 * M * M + M * (2 * D + 5 * Do + 5)
+    pts = 1.0 * (w.T - 1) * w.N
+    fl = {'forward_pass': pts * F(w.M, w.D, w.dim_x)}
+    if mode == 'train':
+        stash = eng.stash
+        fa = 2.0 if eng.last_ws.a2s_f is not None else 3.0            # saved A2 tiles: the reverse sweep costs 2 F
+        outer = 2.0 * w.M * w.M if stash else 0.0                      # stash mode: A2bar K^T runs in the contraction
+        fl['forward_pass_adjoint'] = pts * (fa * F(w.M, w.D, w.dim_x) - outer)
+        if stash:
+            fl['stash_contraction'] = pts * outer
+    name = max(ms, key=lambda k: ms[k])
+    ach = fl[name] / (ms[name] * 1e-3) / 1e12
+    steps_per_s = args.steps / dt
+    rec = {
+        'metric': 'ELBO steps/sec', 'value': steps_per_s, 'unit': 'steps/s (one step = one %d-sequence mini-batch per GPU)' % w.B,
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'states_per_sec': steps_per_s * w.B * w.T,
+        'config': {'workload': '%s shape, %s %s step: M=%d T=%d B=%d/GPU S=%d dim_x=%d dim_u=%d dim_y=%d recog_len=%d, GRU(16) '
+                               'recognition model' % (w.name, {'half': 'CBFSSMHALF', 'prssm': 'PRSSM'}[args.model], mode, w.M, w.T,
+                                                      w.B, w.S, w.dim_x, w.dim_u, w.dim_y, w.recog_len),
+                   'model': args.model, 'mode': mode, 'global_batch': w.B, 'seq_len': w.T, 'particles': w.S, 'parallelism': 'dp1'},
+        'loss': loss,
+        'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': ach / F64_MFMA_PEAK_TFLOPS, 'traffic': None, 'kernel': name,
+                     'kernel_ms': ms, 'kernel_tflops': {k: fl[k] / (ms[k] * 1e-3) / 1e12 for k in ms}, 'launches': n,
+                     'note': 'one GP (gp_f), no backward runs: one workgroup per 16-chain group walks the T - 1 steps (%d groups on '
+                             'the chip\'s CUs); full launches, HIP events on the launch stream' % ((w.N + 15) // 16)},
+        'cpu_baseline': None,
+    }
+    print(json.dumps(rec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -170,6 +258,9 @@ def main():
                     help='init: run-script initial values (cond(K_mm) 1..700, dense GP form).  trained: the trained-like '
                          'family of the parity sweep (cbfssm.synthetic.trained_like_params, lengthscales x 64, inducing means '
                          '0.1: cond 3e7, above the automatic switch to the two-triangular GP form)')
+    ap.add_argument('--model', default='cbfssm', choices=['cbfssm', 'half', 'prssm'],
+                    help='cbfssm: the headline path.  half / prssm: the forward-only variants (CBFSSMHALF, cbfssmhalf.py; the PR-SSM '
+                         'baseline, prssm.py) on the same workload shapes: one GP, no backward runs, GRU(16) recognition model')
     ap.add_argument('--dtype', default='float64', choices=['float64', 'float32'],
                     help='float32: the float32-arithmetic passes and adjoint (NOT the headline: the reference computes in '
                          'float64)')
@@ -198,6 +289,9 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
+    if args.model != 'cbfssm':
+        assert world == 1 and args.dtype == 'float64', '--model half|prssm: one GPU, float64'
+        return bench_variant(args, dev)
     default_workload = args.workload is None
     if default_workload:
         args.workload = 'C3'          # the same workload at every N: a 1 -> N series of `value` is one workload
@@ -350,8 +444,67 @@ def main():
     # ---- per-kernel timing of the time-loop kernels with HIP events on the launch stream
     roof = None
     if rank == 0 and args.dtype == 'float32':
-        roof = {'bound': 'mfma', 'achieved': None, 'peak': None, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None,
-                'note': 'float32 arithmetic (forward evaluation and adjoint): whole-step time only'}
+        # the float32-arithmetic time loops (cbfssm_*_pass_f32, cbfssm_*_pass_bwd_f32), each timed by itself with HIP events on
+        # the launch stream and priced against the float32 matrix peak (v_mfma_f32_16x16x4_f32)
+        import ctypes as C
+        l = lib.load()
+        st = ops._stream()
+        noise = draw_noise()
+        prob = lib.make_problem(w.B, w.S, w.T, w.dim_x, w.dim_u, w.dim_y, w.M, cfg['recog_len'], cfg['k_factor'], True)
+        if mode == 'train':
+            eng2 = stepper.engine
+            eng2.loss_and_grads(stepper.params, u, y, noise)          # fills the trajectories, (fmean, fvar) and the packs
+            ws = eng2.last_ws
+            cst = eng2._constrained({k: v for k, v in stepper.params.items()})
+            var_x, var_y, pack_f, pack_b = cst['var_x'], cst['var_y'], eng2.pack_f, eng2.pack_b
+        else:
+            eng2 = ops.HipElbo(cfg, dev, dtype='float32')
+            eng2.prepare(params)
+            ws = eng2.run(u, y, noise, condition=True, keep_h=True)
+            var_x, var_y, pack_f, pack_b = eng2.var_x, eng2.var_y, eng2.pack_f, eng2.pack_b
+        b32f, b32b = (C.c_void_p(pk.pack_f32().data_ptr()) for pk in (pack_f, pack_b))
+        lf_, lb_ = C.byref(pack_f.layout), C.byref(pack_b.layout)
+        P = ops._ptr
+
+        def time32(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+
+        def F(M, D, Do):   # algorithmic FLOPs of one GP point evaluation
+            return 2 * M * M + M * (2 * D + 5 * Do + 5)
+        pts_f, pts_b = 1.0 * (w.T - 1) * N, 2.0 * w.T * N
+        reps = 10 if w.M <= 200 else 2
+        kern = {
+            'backward_pass_f32': (time32(lambda: lib.check(l.cbfssm_backward_pass_f32(
+                C.byref(prob), lb_, b32b, P(var_x), P(u), P(y), P(noise['hid_b']), P(noise['eps_b']), P(ws.y2), P(ws.h_all),
+                P(ws.fmv_b), P(ws.ent_part), st), 'bwd32'), reps), pts_b * F(w.M, w.D, w.dim_out_b)),
+            'forward_pass_f32': (time32(lambda: lib.check(l.cbfssm_forward_pass_f32(
+                C.byref(prob), lf_, b32f, P(var_x), P(var_y), P(u), P(y), P(ws.y2), P(noise['eps_f']), P(ws.x), P(ws.fmv_f),
+                P(ws.kl_part), st), 'fwd32'), reps), pts_f * F(w.M, w.D, w.dim_x))}
+        if mode == 'train':
+            cL, cE = float(cfg['loss_factors'][0]) / w.S, float(cfg['loss_factors'][1]) / w.S
+            # (the float32 adjoint keeps no tiles: it recomputes the kernel tile and A2 -- 3 F per GP evaluation)
+            kern['forward_pass_adjoint_f32'] = (time32(lambda: lib.check(l.cbfssm_forward_pass_bwd_f32(
+                C.byref(prob), lf_, b32f, P(var_x), P(var_y), P(u), P(y), P(ws.y2), P(noise['eps_f']), P(ws.x), P(ws.fmv_f), cL,
+                P(ws.gy2), P(ws.gpart_f), st), 'rev fwd32'), max(1, reps // 2)), 3.0 * pts_f * F(w.M, w.D, w.dim_x))
+            kern['backward_pass_adjoint_f32'] = (time32(lambda: lib.check(l.cbfssm_backward_pass_bwd_f32(
+                C.byref(prob), lb_, b32b, P(var_x), P(u), P(y), P(noise['hid_b']), P(noise['eps_b']), P(ws.h_all), P(ws.fmv_b),
+                P(ws.gy2), cE, P(ws.gpart_b), st), 'rev bwd32'), max(1, reps // 2)), 3.0 * pts_b * F(w.M, w.D, w.dim_out_b))
+        name = max(kern, key=lambda k: kern[k][0])
+        ach = kern[name][1] / kern[name][0] / 1e12
+        roof = {'bound': 'mfma', 'achieved': ach, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / F32_MFMA_PEAK_TFLOPS, 'traffic': None, 'kernel': name,
+                'kernel_ms': {k: v[0] * 1e3 for k, v in kern.items()},
+                'kernel_tflops': {k: v[1] / v[0] / 1e12 for k, v in kern.items()},
+                'note': 'float32 arithmetic (v_mfma_f32_16x16x4_f32, 32 cycles per SIMD: 157.3 TFLOP/s); full launches; the '
+                        'adjoint recomputes the kernel tile and A2 and is priced at 3 F per GP evaluation'}
     elif rank == 0:
         import ctypes as C
         l = lib.load()

@@ -329,17 +329,38 @@ class HipElboGrad:
                  'info': ws.out[7]}
         if self.fused_tail:
             Mp = self.pack_f.layout.Mp
-            rc = lib.cbfssm_train_tail_f64(C.byref(self.pl), C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
-                                           C.byref(self.pack_b.layout), _ptr(self.pack_b.buf), _ptr(red), _ptr(gB_f),
-                                           _ptr(gB_b), 0, _ptr(pflat), _ptr(self.cflat), _ptr(self.tail_work),
-                                           _ptr(self.gflat), st)
-            _l.check(rc, 'cbfssm_train_tail_f64')
+            # float32 adjoint: the matrix section is G = K^-1 (d loss / d K^-1) K^-1 (full up to 10 row blocks, the
+            # lower-triangular blocks of G + G^T above: include/cbfssm_hip.h)
+            g_mode = 0 if not self.f32 else (2 if self.pack_f.layout.NBLK >= 13 else 1)
+            rc = lib.cbfssm_train_tail_g_f64(C.byref(self.pl), C.byref(self.pack_f.layout), _ptr(self.pack_f.buf),
+                                             C.byref(self.pack_b.layout), _ptr(self.pack_b.buf), _ptr(red), _ptr(gB_f),
+                                             _ptr(gB_b), 0, g_mode, _ptr(pflat), _ptr(self.cflat), _ptr(self.tail_work),
+                                             _ptr(self.gflat), st)
+            _l.check(rc, 'cbfssm_train_tail_g_f64')
             return loss, _flat_views(self.gflat, self.pl, self.dim_u), terms
 
         # ---- once-per-step adjoints and the chain through the positivity transforms (tensor-library restatement)
         grads = {}
         gvx = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
         gvy = torch.zeros(self.dim_x, dtype=torch.float64, device=dev)
+        if self.f32:
+            # the float32 adjoint's matrix section holds G = K^-1 (d loss / d K^-1) K^-1 (include/cbfssm_hip.h); this
+            # restatement expects d loss / d K^-1 = K G K, K = K_mm + jitter I
+            def kinv_adjoint(img, pack):
+                nb, M = pack.layout.NBLK, pack.M
+                G = _unpack_c(img, nb, nb)
+                if nb >= 13:             # lower-triangular blocks of G + G^T (diagonal blocks: of G)
+                    blk = torch.arange(16 * nb, device=dev) // 16
+                    G = torch.where(blk[:, None] >= blk[None, :], G, torch.zeros_like(G))
+                G = 0.5 * (G + G.T)[:M, :M]
+                K = pack.Kmm + pack.scal[_l.SCAL_JITTER] * torch.eye(M, dtype=torch.float64, device=dev)
+                Bd = torch.zeros(16 * nb, 16 * nb, dtype=torch.float64, device=dev)
+                Bd[:M, :M] = K @ G @ K
+                return Bd.view(nb, 4, 4, nb, 16).permute(0, 3, 1, 2, 4).reshape(-1)
+            nbf, nbb = self.pack_f.layout.NBLK, self.pack_b.layout.NBLK
+            gB_f = kinv_adjoint(gB_f if gB_f is not None else red[2 * nbf * 256:2 * nbf * 256 + nbf * nbf * 256], self.pack_f)
+            gB_b = kinv_adjoint(gB_b if gB_b is not None else red[sf + 2 * nbb * 256:sf + 2 * nbb * 256 + nbb * nbb * 256],
+                                self.pack_b)
         for g, pack, slab, Do, gBx in (('f', self.pack_f, red[:sf], self.dim_x, gB_f),
                                        ('b', self.pack_b, red[sf:sf + sb], self.dob, gB_b)):
             gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(pack, slab, p[g + '.zeta_pos'], c[g + '.ls'], c[g + '.var'],
@@ -517,24 +538,12 @@ class HipElboGrad:
             e3.record(s1)
             rbwd(p_rest, st0)
             s0.wait_event(e3)
-        def to_kinv_adjoint(img, pack):
-            """The float32 adjoint accumulates G = K^-1 (d loss / d K^-1) K^-1 directly (cbfssm_rev32.hip, phase F); the
-            float64 tail expects d loss / d K^-1 = K G K with K = K_mm + jitter I (two M x M float64 products, in place in
-            the C-layout image)."""
-            nb, M = pack.layout.NBLK, pack.M
-            G = _unpack_c(img, nb, nb)[:M, :M]
-            K = pack.Kmm + pack.scal[_l.SCAL_JITTER] * torch.eye(M, dtype=torch.float64, device=self.device)
-            Bd = torch.zeros(16 * nb, 16 * nb, dtype=torch.float64, device=self.device)
-            Bd[:M, :M] = K @ G @ K
-            img.copy_(Bd.view(nb, 4, 4, nb, 16).permute(0, 3, 1, 2, 4).reshape(-1))
-
         if not self.stash:
             assert self.slab32_f == sf and self.slab32_b == sb
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_b), sb, ws.n_b, _ptr(red[sf:sf + sb]), st), 'reduce b')
-            for lo, pack in ((0, self.pack_f), (sf, self.pack_b)):
-                nb = pack.layout.NBLK
-                to_kinv_adjoint(red[lo + 2 * nb * 256:lo + 2 * nb * 256 + nb * nb * 256], pack)
+            # (the matrix section holds G = K^-1 (d loss / d K^-1) K^-1, the data part of d loss / d K_mm itself:
+            #  cbfssm_train_tail_g_f64 takes it as it is, _grads_finish passes g_mode)
             return None, None
         if getattr(self, '_tmp32', None) is None:
             self._tmp32 = torch.zeros(self.slab32_f + self.slab32_b, dtype=torch.float64, device=self.device)
@@ -551,8 +560,6 @@ class HipElboGrad:
             img = red[io:io + nimg]
             img.copy_(t32[og:og + nimg])
             imgs.append(img)
-        to_kinv_adjoint(imgs[0], self.pack_f)
-        to_kinv_adjoint(imgs[1], self.pack_b)
         return imgs[0], imgs[1]
 
     def _adjoint_stash(self, prob, ws, c, u, y, hid_b, eps_b, eps_f, cL, cE, red):
@@ -685,9 +692,10 @@ class HipElboGrad:
         o += NBLK * 256
         if gB_stash is None:
             gB = _unpack_c(slab[o:o + NBLK * NBLK * 256], NBLK, NBLK)[:M, :M]
-            o += NBLK * NBLK * 256
         else:
             gB = _unpack_c(gB_stash, NBLK, NBLK)[:M, :M]           # C-layout image of cbfssm_stash_contract_f64
+        if not self.stash:
+            o += NBLK * NBLK * 256                                 # (the slab of a non-stash tile height has the section)
         gZf = _unpack_c(slab[o:o + NBLK * JB * 256], NBLK, JB)
         o += NBLK * JB * 256
         small = slab[o:o + 128]

@@ -16,7 +16,7 @@ from . import lib as _l
 from . import ops
 from .ops import _ptr, _stream, _f64, tf_forward, GPPack
 from .dist_utils import all_reduce_sum
-from .train import HipElboGrad, LOG2PI, StashContract
+from .train import HipElboGrad, LOG2PI, StashContract, FlatDict
 
 GP_NAMES = ('f.zeta_pos', 'f.zeta_mean', 'f.zeta_var_unc', 'f.variance_unc', 'f.lengthscales_unc')
 RECOG_NAMES = ('recog.gate_kernel', 'recog.gate_bias', 'recog.cand_kernel', 'recog.cand_bias', 'recog.dense_kernel',
@@ -95,8 +95,24 @@ class HipHalfGrad:
         self.slab_f = int(self.pack_f.layout.rev_slab)
         self._ws = {}
         self.last_ws = None
-        # the K_mm / Cholesky / prior-KL adjoint is shared with CBFSSM
+        # the K_mm / Cholesky / prior-KL adjoint is shared with CBFSSM: cbfssm_train_tail_half_f64 (five launches on flat
+        # vectors); CBFSSM_TORCH_TAIL=1 keeps the tensor-library restatement (same numbers, a cross-check)
         self._gp_adjoint = HipElboGrad._gp_adjoint.__get__(self)
+        self.fused_tail = self.slab_f > 0 and not os.environ.get('CBFSSM_TORCH_TAIL')
+        self.gp_names = self.names[:7]                       # the five GP tensors, var_x_unc, var_y_unc: the tail's flat order
+        self.tail_work = None
+
+    def _timed(self, kind, fn):
+        """measurement hook (bench.py --model half|prssm): with a list in self._prof the launch is bracketed by HIP events"""
+        prof = getattr(self, '_prof', None)
+        if prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        prof.append((kind, e0, e1))
+        return rc
 
     def _problem(self, B, T, condition):
         c = self.config
@@ -130,9 +146,9 @@ class HipHalfGrad:
         if self.pack_kl is not None:
             self.pack_kl.prepare(p[pre + 'zeta_pos'], c['ls'], c['var'], p[pre + 'zeta_mean'], c['zvar'], jitter=0.0)
         lay = C.byref(self.pack_f.layout)
-        rc = lib.cbfssm_half_forward_pass_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
-                                              _ptr(u), _ptr(y), _ptr(x0), _ptr(eps_f) if eps_f.numel() else None,
-                                              _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st)
+        rc = self._timed('forward_pass', lambda: lib.cbfssm_half_forward_pass_f64(
+            pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(x0),
+            _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st))
         _l.check(rc, 'cbfssm_half_forward_pass_f64')
         rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(c['var_y']), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part),
                                            _ptr(ws.pred_mean), _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)
@@ -181,7 +197,7 @@ class HipHalfGrad:
             ws.gx0 = torch.zeros(N, prob.dim_x, **f)
             ws.gx_carry = torch.zeros(N, prob.dim_x, **f)
             ws.gpart_f = torch.zeros((ws.n_f + 32) * self.slab_f, **f)
-            ws.red = torch.zeros(self.slab_f + 2 + prob.dim_y, **f)
+            ws.red = torch.zeros(self.slab_f + 3 + prob.dim_y, **f)     # [slab | loglik, kl_x, 0, d loss / d var_y]
             self._ws[key] = ws
         return self._ws[key]
 
@@ -246,12 +262,10 @@ class HipHalfGrad:
         groups = (N + 15) // 16
         gB = None
         if not self.stash:
-            rc = lib.cbfssm_half_forward_pass_bwd_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
-                                                      _ptr(u), _ptr(y), _ptr(eps_f) if eps_f.numel() else None,
-                                                      _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0),
-                                                      _ptr(ws.gpart_f),
-                                                      T - 2, 0, None,
-                                                      None, None, 0, st)
+            rc = self._timed('forward_pass_adjoint', lambda: lib.cbfssm_half_forward_pass_bwd_f64(
+                pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y),
+                _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0),
+                _ptr(ws.gpart_f), T - 2, 0, None, None, None, 0, st))
             _l.check(rc, 'cbfssm_half_forward_pass_bwd_f64')
             _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
         else:
@@ -272,27 +286,23 @@ class HipHalfGrad:
             while True:
                 t_lo = max(0, t_hi - per + 1)
                 cols = groups * max(0, t_hi - t_lo + 1) * 16
-                rc = lib.cbfssm_half_forward_pass_bwd_f64(pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']),
-                                                          _ptr(c['var_y']), _ptr(u), _ptr(y),
-                                                          _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x),
-                                                          _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0), _ptr(ws.gpart_f), t_hi, t_lo, _ptr(ws.gx_carry),
-                                                          _ptr(sa), _ptr(sk), cols, st)
+                rc = self._timed('forward_pass_adjoint', lambda: lib.cbfssm_half_forward_pass_bwd_f64(
+                    pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y),
+                    _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0),
+                    _ptr(ws.gpart_f), t_hi, t_lo, _ptr(ws.gx_carry), _ptr(sa), _ptr(sk), cols, st))
                 _l.check(rc, 'cbfssm_half_forward_pass_bwd_f64')
                 _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, groups, _ptr(tmp), st), 'reduce f')
                 red[:sf] += tmp
                 if cols:
-                    self._contract.add(sa, sk, cols, st)
+                    self._timed('stash_contraction', lambda: self._contract.add(sa, sk, cols, st))
                 t_hi = t_lo - 1
                 if t_hi < 0:
                     break
 
-        # log-likelihood's pull on var_y (cbfssmhalf.py:181-189)
-        vy = c['var_y']
-        ll_d = ws.ll_part.view(-1, self.dim_y).sum(0)
-        sq_d = (-2.0 * ll_d - B * T * self.S * (LOG2PI + torch.log(vy))) * vy
+        # data scalars and the log-likelihood's pull on var_y (cbfssmhalf.py:181-189): tail = [loglik, kl_x, 0, d/d var_y]
         tail = red[sf:]
-        tail[0:2] = ws.out[0:2]
-        tail[2:] = -cL * 0.5 * (sq_d / (vy * vy) - B * T * self.S / vy)
+        _l.check(lib.cbfssm_data_tail_f64(pb, _ptr(c['var_y']), _ptr(ws.ll_part), _ptr(ws.out), cL, _ptr(tail), st),
+                 'cbfssm_data_tail_f64')
         gx0_b = ws.gx0.view(B, self.S, self.dim_x).sum(1)        # d loss / d x_0 per sequence (tiled over S, :87)
         rgrads = {}
         if rnames:
@@ -310,8 +320,38 @@ class HipHalfGrad:
                 t.copy_(flat[o:o + t.numel()].view_as(t))
                 o += t.numel()
 
-        grads = dict(rgrads)
         pre = self.pre
+        loss, terms = self._terms(ws, tail[0:2])
+        if self.fused_tail:
+            # the K_mm -> Cholesky -> K^-1 adjoint, the prior KL and the chain through the positivity transforms in HIP
+            gp = [p[k].reshape(-1) for k in self.gp_names]
+            pflat = getattr(params, 'flat', None)
+            ngp = sum(t.numel() for t in gp)
+            if pflat is None or pflat.device != dev or list(params.keys())[:7] != list(self.gp_names):
+                pflat = torch.cat(gp)
+            lsc = tf_forward(p[pre + 'lengthscales_unc']).reshape(-1)
+            cflat = torch.cat([gp[0], gp[1], c['zvar'].reshape(-1), c['var'], lsc, c['var_x'], c['var_y']])
+            if self.tail_work is None:
+                nw = int(lib.cbfssm_train_tail_half_work_elems(lay))
+                self.tail_work = torch.zeros(nw, dtype=torch.float64, device=dev)
+            gall = torch.zeros(ngp + sum(rgrads[k].numel() for k in rnames), dtype=torch.float64, device=dev)
+            rc = lib.cbfssm_train_tail_half_f64(lay, _ptr(self.pack_f.buf), _ptr(self.pack_kl.buf) if self.pack_kl is not None else None,
+                                                int(lsc.numel() == 1), _ptr(red), _ptr(gB), 0, self.dim_y, _ptr(pflat), _ptr(cflat),
+                                                _ptr(self.tail_work), _ptr(gall), st)
+            _l.check(rc, 'cbfssm_train_tail_half_f64')
+            grads = FlatDict()
+            grads.flat = gall
+            o = 0
+            for k in self.gp_names:
+                grads[k] = gall[o:o + p[k].numel()].view(p[k].shape)
+                o += p[k].numel()
+            for k in rnames:
+                gall[o:o + rgrads[k].numel()] = rgrads[k].reshape(-1)
+                grads[k] = gall[o:o + rgrads[k].numel()].view(rgrads[k].shape)
+                o += rgrads[k].numel()
+            return loss, grads, terms
+
+        grads = dict(rgrads)
         gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(self.pack_f, red[:sf], p[pre + 'zeta_pos'], c['ls'], c['var'],
                                                           p[pre + 'zeta_mean'], c['zvar'], self.dim_x, gB, self.pack_kl)
         grads[pre + 'zeta_pos'] = gz
@@ -323,6 +363,5 @@ class HipHalfGrad:
             gls = gls.sum().reshape(lsu.shape)               # shared lengthscale: its adjoint is the sum over the dims
         grads[pre + 'lengthscales_unc'] = gls * torch.sigmoid(lsu)
         grads['var_x_unc'] = small[0:self.dim_x] * torch.sigmoid(p['var_x_unc'])
-        grads['var_y_unc'] = (small[16:16 + self.dim_y] + tail[2:]) * torch.sigmoid(p['var_y_unc'])
-        loss, terms = self._terms(ws, tail[0:2])
+        grads['var_y_unc'] = (small[16:16 + self.dim_y] + tail[3:]) * torch.sigmoid(p['var_y_unc'])
         return loss, grads, terms

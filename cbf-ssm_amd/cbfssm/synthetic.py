@@ -136,6 +136,34 @@ def make_params(w: Workload, seed=1):
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in p.items()}
 
 
+def make_variant_params(w: Workload, variant='half', recog='rnn', seed=1):
+    """(config, initial parameters) of the forward-only variants at run-script initial values: CBFSSMHALF
+    (cbfssm/model/cbfssmhalf.py:20-47,82-93: gp_f only, var_y with dim_y entries, GRU(16) recognition model with TF's
+    glorot-uniform / GRUCell initial values) or PRSSM (cbfssm/model/prssm.py:28-47: one shared lengthscale)."""
+    cfg = w.model_config()
+    cfg['var_y'] = np.asarray([w.var_y] * w.dim_y)
+    cfg['recog_model'] = recog
+    base = make_params(w, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    if variant == 'prssm':
+        p = {k[2:]: v for k, v in base.items() if k.startswith('f.') and 'lengthscales' not in k}
+        p['lengthscales_unc'] = softplus_inverse(np.asarray([w.gp_len]))
+    else:
+        p = {k: v for k, v in base.items() if k.startswith('f.')}
+    p['var_x_unc'] = base['var_x_unc']
+    p['var_y_unc'] = softplus_inverse(cfg['var_y'])
+
+    def glorot(fan_in, fan_out):
+        lim = np.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, size=(fan_in, fan_out))
+    if recog == 'rnn':
+        n_in, H = w.dim_u + w.dim_y, 16
+        p.update({'recog.gate_kernel': glorot(n_in + H, 2 * H), 'recog.gate_bias': np.ones(2 * H),
+                  'recog.cand_kernel': glorot(n_in + H, H), 'recog.cand_bias': np.zeros(H),
+                  'recog.dense_kernel': glorot(H, w.dim_x), 'recog.dense_bias': np.zeros(w.dim_x)})
+    return cfg, {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in p.items()}
+
+
 def perturb_params(p, seed=3, scale=0.2):
     """Move every parameter off its symmetric initial value (so per-dimension bugs cannot hide)."""
     rng = np.random.default_rng(seed)

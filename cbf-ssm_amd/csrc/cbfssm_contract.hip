@@ -195,7 +195,10 @@ __global__ __launch_bounds__(64 * ((NBLK + 1) / 2)) void stash_contract2_kernel(
 // step against 4.2 ms here).
 constexpr int tri_row(int b) { int i = 0; while ((i + 1) * (i + 2) / 2 <= b) ++i; return i; }
 constexpr int tri_col(int b) { return b - tri_row(b) * (tri_row(b) + 1) / 2; }
-constexpr int sym_waves(int) { return 8; }
+#ifndef CBF_SYM_WAVES13
+#define CBF_SYM_WAVES13 8
+#endif
+constexpr int sym_waves(int nblk) { return nblk <= 13 ? CBF_SYM_WAVES13 : 8; }
 // workgroups per slot slice: one holds the whole triangle up to 16 row blocks (17 accumulator tiles per wave); at 20 the 210
 // tiles go to two workgroups of eight waves (13-14 tiles each: 27 per wave would spill), the first of which needs -- and
 // stages -- only the image rows of its own block rows

@@ -55,81 +55,63 @@ struct Rev32Args {
     int group0, gtotal;    // chain-group split: this launch covers groups [group0, group0 + gridDim.x) of gtotal
 };
 
-// SYMG accumulation of one block row: S[row][j] += C_row A2_j^T + A2_row C_j^T for j = J..row, two blocks at a time (their
-// MFMAs alternate between two accumulators).  cT / aT: the row's C and A2 rows as A operands [m][k = chain]; the column
-// blocks' rows as B operands [k = chain][m] come from the same two LDS tiles (an A-operand image of X is the B-operand
-// image of X^T).  The diagonal block takes C A2^T only; the host symmetrises.
-template <int ROW, int J, int OFF, int NG>
-__device__ __forceinline__ void symg_row(f4 (&gS)[NG], const float (&cT)[4], const float (&aT)[4], const float* Ct, const float* A2k,
-                                         int g, int nl)
+// SYMG accumulation.  Wave w of a two-row-blocks-per-wave tile owns the block rows R1 = NBLK - 1 - w and R0 = w < R1 of the
+// lower triangle: NBLK + 1 accumulator tiles, tile K = block (R1, K) for K <= R1 and block (R0, K - R1 - 1) above.  The tile
+// INDEX is a constant in the source (the accumulators stay in registers); which block a tile is depends on the wave, so the
+// LDS addresses of its column operands and the "diagonal block" test are wave-uniform run-time values -- one code path for
+// every wave.  (First version: one statically indexed instantiation per wave behind an if-chain on w; the merged register
+// webs of ten instantiations cost 300 more spilled registers at 20 row blocks and the pass was slower than the two it
+// replaced.)   S[row][col] += C_row A2_col^T + A2_row C_col^T; the diagonal block takes C A2^T only, the tail symmetrises.
+// cT / aT: the row's C and A2 rows as A operands [m][k = chain]; the column blocks' rows as B operands [k = chain][m] come
+// from the same two LDS tiles (an A-operand image of X is the B-operand image of X^T).
+template <int NBLK, int K>
+__device__ __forceinline__ void symg_tiles(f4 (&gS)[NBLK + 1], int R0, int R1, const float (&c1)[4], const float (&a1)[4],
+                                           const float (&c0)[4], const float (&a0)[4], const float* Ct, const float* A2k, int g, int nl)
 {
     constexpr int PD = 17;
-    if constexpr (J <= ROW) {
-        if constexpr (J + 1 <= ROW) {
+    if constexpr (K <= NBLK) {
+        if (K <= R1) {
+            const float* pa = A2k + (16 * K + nl) * PD + g;
+            const float* pc = Ct + (16 * K + nl) * PD + g;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float a0 = A2k[(16 * J + nl) * PD + 4 * s + g], a1 = A2k[(16 * (J + 1) + nl) * PD + 4 * s + g];
-                gS[OFF + J] = CBF_MFMA32(cT[s], a0, gS[OFF + J]);
-                gS[OFF + J + 1] = CBF_MFMA32(cT[s], a1, gS[OFF + J + 1]);
-                const float c0 = Ct[(16 * J + nl) * PD + 4 * s + g];
-                gS[OFF + J] = CBF_MFMA32(aT[s], c0, gS[OFF + J]);
-                if constexpr (J + 1 < ROW) {
-                    const float c1 = Ct[(16 * (J + 1) + nl) * PD + 4 * s + g];
-                    gS[OFF + J + 1] = CBF_MFMA32(aT[s], c1, gS[OFF + J + 1]);
-                }
+            for (int s = 0; s < 4; ++s) gS[K] = CBF_MFMA32(c1[s], pa[4 * s], gS[K]);
+            if (K != R1) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) gS[K] = CBF_MFMA32(a1[s], pc[4 * s], gS[K]);
             }
-            symg_row<ROW, J + 2, OFF, NG>(gS, cT, aT, Ct, A2k, g, nl);
-        } else {
+        } else if (R1 > R0) {
+            const int col = K - R1 - 1;                                   // (<= R0 for every K <= NBLK)
+            const float* pa = A2k + (16 * col + nl) * PD + g;
+            const float* pc = Ct + (16 * col + nl) * PD + g;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float a0 = A2k[(16 * J + nl) * PD + 4 * s + g];
-                gS[OFF + J] = CBF_MFMA32(cT[s], a0, gS[OFF + J]);                  // (J == ROW: the diagonal block)
+            for (int s = 0; s < 4; ++s) gS[K] = CBF_MFMA32(c0[s], pa[4 * s], gS[K]);
+            if (col != R0) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) gS[K] = CBF_MFMA32(a0[s], pc[4 * s], gS[K]);
             }
         }
+        symg_tiles<NBLK, K + 1>(gS, R0, R1, c1, a1, c0, a0, Ct, A2k, g, nl);
     }
 }
-
-// wave WID of a SYMG tile: block rows R1 = NBLK - 1 - WID (tiles gS[0 .. R1]) and R0 = WID < R1 (tiles gS[R1 + 1 .. NBLK])
-template <int NBLK, int WID>
-__device__ __forceinline__ void symg_accum(f4 (&gS)[NBLK + 1], const float* Ct, const float* A2k, int g, int nl)
+template <int NBLK, int K>
+__device__ __forceinline__ void symg_store(const f4 (&gS)[NBLK + 1], int R0, int R1, double* gBslab, int img)
 {
-    constexpr int PD = 17, R0 = WID, R1 = NBLK - 1 - WID;
-    float cT[4], aT[4];
+    if constexpr (K <= NBLK) {
+        const bool hi = (K <= R1);
+        if (hi || R1 > R0) {
+            const int row = hi ? R1 : R0, col = hi ? K : K - R1 - 1;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { cT[s] = Ct[(16 * R1 + nl) * PD + 4 * s + g]; aT[s] = A2k[(16 * R1 + nl) * PD + 4 * s + g]; }
-    symg_row<R1, 0, 0, NBLK + 1>(gS, cT, aT, Ct, A2k, g, nl);
-    if constexpr (R1 > R0) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { cT[s] = Ct[(16 * R0 + nl) * PD + 4 * s + g]; aT[s] = A2k[(16 * R0 + nl) * PD + 4 * s + g]; }
-        symg_row<R0, 0, R1 + 1, NBLK + 1>(gS, cT, aT, Ct, A2k, g, nl);
-    }
-}
-template <int NBLK, int WID>
-__device__ __forceinline__ void symg_store(const f4 (&gS)[NBLK + 1], double* gBslab, int img)
-{
-    constexpr int R0 = WID, R1 = NBLK - 1 - WID;
-#pragma unroll
-    for (int j = 0; j <= R1; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gBslab[(R1 * NBLK + j) * 256 + img + r * 16] = double(gS[j][r]);
-    if constexpr (R1 > R0) {
-#pragma unroll
-        for (int j = 0; j <= R0; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gBslab[(R0 * NBLK + j) * 256 + img + r * 16] = double(gS[R1 + 1 + j][r]);
-    }
-}
-template <int NBLK, int WID, bool STORE>
-__device__ __forceinline__ void symg_dispatch(int w, f4 (&gS)[NBLK + 1], const float* Ct, const float* A2k, int g, int nl,
-                                              double* gBslab, int img)
-{
-    if constexpr (WID < (NBLK + 1) / 2) {
-        if (w == WID) {                                    // (w is wave-uniform: a scalar branch)
-            if constexpr (STORE) symg_store<NBLK, WID>(gS, gBslab, img);
-            else symg_accum<NBLK, WID>(gS, Ct, A2k, g, nl);
-        } else {
-            symg_dispatch<NBLK, WID + 1, STORE>(w, gS, Ct, A2k, g, nl, gBslab, img);
+            for (int r = 0; r < 4; ++r) gBslab[(row * NBLK + col) * 256 + img + r * 16] = double(gS[K][r]);
         }
+        symg_store<NBLK, K + 1>(gS, R0, R1, gBslab, img);
+    }
+}
+template <int N, int K>
+__device__ __forceinline__ void symg_zero(f4 (&gS)[N])
+{
+    if constexpr (K < N) {
+        gS[K] = f4{0, 0, 0, 0};
+        symg_zero<N, K + 1>(gS);
     }
 }
 
@@ -213,8 +195,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
 
     f4 gMu[RB], gS2[RB], gZ[RB][JB], gB[RB][NCB];
     f4 gS[SYMG ? NBLK + 1 : 1];
-#pragma unroll
-    for (int k = 0; k < (SYMG ? NBLK + 1 : 1); ++k) gS[k] = f4{0, 0, 0, 0};
+    symg_zero<(SYMG ? NBLK + 1 : 1), 0>(gS);
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         gMu[i] = f4{0, 0, 0, 0};
@@ -666,7 +647,16 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         __syncthreads();                                                                           // 5
         // SYMG: S += C A2^T + A2 C^T on this wave's block rows, both tiles complete and untouched until the next step's
         // phase E / F -- in the shadow of phases G / D, which are vector latency on the first waves
-        if constexpr (SYMG) symg_dispatch<NBLK, 0, false>(w, gS, Ct, A2k, g, nl, nullptr, 0);
+        if constexpr (SYMG) {
+            const int R0 = w, R1 = NBLK - 1 - w;
+            float c1[4], a1[4], c0[4], a0[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                c1[s] = Ct[(16 * R1 + nl) * PD + 4 * s + g]; a1[s] = A2k[(16 * R1 + nl) * PD + 4 * s + g];
+                c0[s] = Ct[(16 * R0 + nl) * PD + 4 * s + g]; a0[s] = A2k[(16 * R0 + nl) * PD + 4 * s + g];
+            }
+            symg_tiles<NBLK, 0>(gS, R0, R1, c1, a1, c0, a0, Ct, A2k, g, nl);
+        }
 
         // ---- G: input adjoint, carried to the next reverse step.  Lane (g, nl) of group gi = 4 jb + q holds input row
         // j = 16 jb + 4 g + q of chain nl (register q of the xbar tile)
@@ -761,7 +751,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         }
     }
     // (SYMG: the lower-triangular blocks; the blocks above the diagonal of the slab section are never written and stay zero)
-    if constexpr (SYMG) symg_dispatch<NBLK, 0, true>(w, gS, nullptr, nullptr, g, nl, slab + SL::gB, img);
+    if constexpr (SYMG) symg_store<NBLK, 0>(gS, w, NBLK - 1 - w, slab + SL::gB, img);
     if (!first) return;
     for (int i = tid; i < 192; i += NT) slab[SL::small + i] = 0.0;
     __syncthreads();

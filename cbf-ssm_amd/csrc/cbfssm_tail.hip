@@ -39,6 +39,13 @@ struct GpTail {
     double* g_var;            // [1]
     double* g_ls;             // [D]
     int M, D, Do, NBLK, JB, stash;
+    const double* Kkl;        // PR-SSM: the prior-KL terms use THIS inverse, of K_mm without jitter (prssm.py:81-82); NULL: Kinv
+    double* T2;               // PR-SSM scratch [M][M]: Kkl B_KL
+    int shared_ls;            // PR-SSM: one lengthscale for all input dimensions (prssm.py:40): ls / ls_unc / g_ls have one entry
+    int gmode;                // 0: the image holds d loss / d K^-1 (float64 adjoint).  1, 2: it holds G = the K_mm adjoint's data
+                              // part itself, K^-1 (d loss / d K^-1) K^-1 (float32 adjoint, cbfssm_rev32.hip) -- 1: the full
+                              // matrix, 2: only its lower-triangular 16 x 16 blocks, as S = C A2^T + A2 C^T (diagonal blocks:
+                              // C A2^T); either way only the symmetric part of G enters
 };
 
 struct TailArgs {
@@ -49,6 +56,8 @@ struct TailArgs {
     double* g_vy;
     const double* tail;       // [3 + dim_y]: loglik, kl_x, entropy, d loss/d var_y from the log-likelihood
     int dim_x, dim_y;
+    int ngp;                  // 2: CBFSSM (gp_f, gp_b); 1: the forward-only variants (CBFSSMHALF, PRSSM: gp_f only)
+    int n_vy;                 // entries of var_y: dim_x (CBFSSM, cbfssm.py:60-63) or dim_y (the forward-only variants)
 };
 
 __device__ __forceinline__ double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
@@ -71,12 +80,36 @@ __device__ __forceinline__ double block_sum_t(double v, double* red, int tid, in
     return s;
 }
 
+// the data part's image, element (k, j)
+__device__ __forceinline__ double img_elem(const GpTail& p, int k, int j)
+{
+    if (p.gB_dense) return (p.gB_ld > 0) ? p.gB_dense[int64_t(k) * p.gB_ld + j] : c_image(p.gB_dense, p.NBLK, k, j);
+    return c_image(p.slab + 2 * p.NBLK * 256, p.NBLK, k, j);
+}
+// gmode 1, 2: the symmetric part of G, element (k, j)
+__device__ __forceinline__ double gsym_elem(const GpTail& p, int k, int j)
+{
+    if (p.gmode == 2) {
+        const int bk = k >> 4, bj = j >> 4;
+        return 0.5 * ((bk >= bj ? img_elem(p, k, j) : 0.0) + (bj >= bk ? img_elem(p, j, k) : 0.0));
+    }
+    return 0.5 * (img_elem(p, k, j) + img_elem(p, j, k));
+}
+
 // G = Kinvbar (data) + Kinvbar (prior KL):  0.5 (diag(sum_d zvar) + zmean zmean^T)          (gp_tf.py:163-172)
+// (gmode != 0: the prior-KL part only -- the data part arrives K^-1-applied and is added in stage 1)
+__device__ __forceinline__ double kl_elem(const GpTail& p, int k, int j)
+{
+    double dot = 0.0;
+    for (int d = 0; d < p.Do; ++d) dot = fma(p.zmean[k * p.Do + d], p.zmean[j * p.Do + d], dot);
+    if (k == j)
+        for (int d = 0; d < p.Do; ++d) dot += p.zvar[k * p.Do + d];
+    return 0.5 * dot;
+}
 __device__ __forceinline__ double g_elem(const GpTail& p, int k, int j)
 {
-    double v;
-    if (p.gB_dense) v = (p.gB_ld > 0) ? p.gB_dense[int64_t(k) * p.gB_ld + j] : c_image(p.gB_dense, p.NBLK, k, j);
-    else v = c_image(p.slab + 2 * p.NBLK * 256, p.NBLK, k, j);
+    const double v = p.gmode ? 0.0 : img_elem(p, k, j);
+    if (p.Kkl) return v;                                  // (PR-SSM: the prior-KL part goes through Kkl, tail_gemm<3>)
     double dot = 0.0;
     for (int d = 0; d < p.Do; ++d) dot = fma(p.zmean[k * p.Do + d], p.zmean[j * p.Do + d], dot);
     if (k == j)
@@ -106,7 +139,7 @@ __global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
             double av = 0.0;
             if (i < M && k0 + tx < M) {
                 const int k = k0 + tx;
-                av = km ? p.Kinv[int64_t(i) * M + k] : -0.5 * (p.G2[int64_t(i) * M + k] + p.G2[int64_t(k) * M + i]);
+                av = km ? (p.Kkl ? p.Kkl : p.Kinv)[int64_t(i) * M + k] : -0.5 * (p.G2[int64_t(i) * M + k] + p.G2[int64_t(k) * M + i]);
             }
             As[ty][tx] = av;
             double bv = 0.0;
@@ -124,22 +157,57 @@ __global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
         return;
     }
     if (int(blockIdx.x) * 16 >= M) return;
-    const double* A = (STAGE == 0) ? p.Kinv : p.T;
+    if constexpr (STAGE == 3) {
+        if (!p.Kkl) return;                               // PR-SSM only: T2 = Kkl B_KL
+    }
+    const double* A = (STAGE == 0) ? p.Kinv : (STAGE == 3 ? p.Kkl : p.T);
     double acc = 0.0;
     for (int k0 = 0; k0 < M; k0 += 16) {
         As[ty][tx] = (i < M && k0 + tx < M) ? A[int64_t(i) * M + k0 + tx] : 0.0;
         double b = 0.0;
-        if (k0 + ty < M && j < M) b = (STAGE == 0) ? g_elem(p, k0 + ty, j) : p.Kinv[int64_t(k0 + ty) * M + j];
+        if (k0 + ty < M && j < M)
+            b = (STAGE == 0) ? g_elem(p, k0 + ty, j) : (STAGE == 3 ? kl_elem(p, k0 + ty, j) : p.Kinv[int64_t(k0 + ty) * M + j]);
         Bs[ty][tx] = b;
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) acc = fma(As[ty][kk], Bs[kk][tx], acc);
         __syncthreads();
     }
+    double acc2 = 0.0;                                    // PR-SSM, stage 1: (Kkl B_KL) Kkl
+    if (STAGE == 1 && p.Kkl) {
+        for (int k0 = 0; k0 < M; k0 += 16) {
+            As[ty][tx] = (i < M && k0 + tx < M) ? p.T2[int64_t(i) * M + k0 + tx] : 0.0;
+            Bs[ty][tx] = (k0 + ty < M && j < M) ? p.Kkl[int64_t(k0 + ty) * M + j] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc2 = fma(As[ty][kk], Bs[kk][tx], acc2);
+            __syncthreads();
+        }
+    }
     if (i < M && j < M) {
         if (STAGE == 0) p.T[int64_t(i) * M + j] = acc;
-        else {
+        else if (STAGE == 3) p.T2[int64_t(i) * M + j] = acc;
+        else if (p.Kkl) {
+            // K_mm adjoint with the jitter-free prior (prssm.py:81-82,96): -K^-1 B K^-1 - Kkl B_KL Kkl + 0.5 Do Kkl, and
+            // tr(Kbar K_mm) = -tr(K^-1 B) + jitter tr(K^-1 B K^-1) - tr(Kkl B_KL) + 0.5 Do M   (Kkl K_mm = I)
+            p.G2[int64_t(i) * M + j] = (-acc - acc2 + 0.5 * p.Do * p.Kkl[int64_t(i) * M + j]) * p.Kmm[int64_t(i) * M + j];
+            if (i == j)
+                p.dv[i] = -p.T[int64_t(i) * M + i] + p.scal[CBFSSM_SCAL_JITTER] * acc - p.T2[int64_t(i) * M + i] + 0.5 * p.Do;
+        } else {
             const double kinv = p.Kinv[int64_t(i) * M + j];
+            double tdiag = (i == j) ? p.T[int64_t(i) * M + i] : 0.0;
+            if (p.gmode) {
+                // K^-1 (B + B_KL) K^-1 = G + K^-1 B_KL K^-1, and the diagonal of K^-1 B = G (K_mm + jitter I); the jitter
+                // terms of the trace below cancel between the two
+                const double gs = gsym_elem(p, i, j);
+                if (i == j) {
+                    double d = 0.0;
+                    for (int k = 0; k < M; ++k) d = fma(gsym_elem(p, i, k), p.Kmm[int64_t(k) * M + i], d);
+                    tdiag += d;
+                }
+                acc += gs;
+                if (i == j) tdiag += p.scal[CBFSSM_SCAL_JITTER] * gs;
+            }
             p.G2[int64_t(i) * M + j] = (-acc + 0.5 * p.Do * kinv) * p.Kmm[int64_t(i) * M + j];
             // d loss / d sigma^2 needs sum_ij Kbar_ij K_mm,ij = tr(Kbar K_mm).  Summing the entries of G2 cancels twice
             // (entries of K^-1 G K^-1 are of order cond^2 |G|): with K^-1 K_mm = I - jitter K^-1 the same trace is
@@ -147,7 +215,7 @@ __global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
             // whose terms are of order cond |G| only (measured on a trained-like K_mm with cond 3e7: 3.5e-2 -> see DESIGN).
             if (i == j) {
                 const double jit = p.scal[CBFSSM_SCAL_JITTER];
-                p.dv[i] = -p.T[int64_t(i) * M + i] + jit * acc + 0.5 * p.Do * (1.0 - jit * kinv);
+                p.dv[i] = -tdiag + jit * acc + 0.5 * p.Do * (1.0 - jit * kinv);
             }
         }
     }
@@ -161,6 +229,7 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
     const int tid = threadIdx.x, NT = 256;
     __shared__ double wsrow[320];
     __shared__ double red[8];
+    __shared__ double glsj[32];
     const double* gMu = p.slab;
     const double* gS2 = p.slab + NBLK * 256;
     const double* gZ = p.slab + 2 * NBLK * 256 + (p.stash ? 0 : NBLK * NBLK * 256);
@@ -188,14 +257,25 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
         const int i = idx / D, j = idx - i * D;
         const double zs = p.Zs[idx];
         const double gzt = c_image(gZ, JB, i, j) - zs * c_image(gZ, JB, i, D) + 2.0 * (wsrow[i] * zs - WZ[idx]);
-        p.g_z[idx] = gzt / p.ls[j];
+        p.g_z[idx] = gzt / p.ls[p.shared_ls ? 0 : j];
     }
     __syncthreads();
     for (int j = wv; j < D; j += NT / 64) {              // one wave per column: lanes over the rows (fixed order)
         double s = 0.0;
         for (int i = l; i < M; i += 64) s += p.g_z[i * D + j] * p.Zs[i * D + j];      // = Z~bar o z~ / ls
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (l == 0) p.g_ls[j] = -(s + small[32 + j] / p.ls[j]) * sigmoid(p.ls_unc[j]);
+        if (l == 0) {
+            if (p.shared_ls) glsj[j] = -(s + small[32 + j] / p.ls[0]);
+            else p.g_ls[j] = -(s + small[32 + j] / p.ls[j]) * sigmoid(p.ls_unc[j]);
+        }
+    }
+    if (p.shared_ls) {                                   // one lengthscale: its adjoint is the sum over the input dimensions
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int j = 0; j < D; ++j) s += glsj[j];
+            p.g_ls[0] = s * sigmoid(p.ls_unc[0]);
+        }
     }
     if (tid == 0) {
         const double var = p.var[0];
@@ -205,19 +285,23 @@ __global__ __launch_bounds__(256) void tail_finish(TailArgs a)
     for (int idx = tid; idx < M * Do; idx += NT) {
         const int i = idx / Do, d = idx - i * Do;
         p.g_mu[idx] = c_image(gMu, 1, i, d) + KM[idx];
-        const double gs2 = c_image(gS2, 1, i, d) + 0.5 * (p.Kinv[int64_t(i) * M + i] - 1.0 / p.zvar[idx]);
+        const double gs2 = c_image(gS2, 1, i, d) + 0.5 * ((p.Kkl ? p.Kkl : p.Kinv)[int64_t(i) * M + i] - 1.0 / p.zvar[idx]);
         p.g_s2[idx] = gs2 * sigmoid(p.zvar_unc[idx]);
     }
     // process / observation noise (workgroup of gp_f): per-dimension sums of both slabs + the log-likelihood's pull
     if (blockIdx.x == 0 && tid < a.dim_x) {
-        const GpTail& pb = a.gp[1];
-        const double* small_b = pb.slab + 2 * pb.NBLK * 256 + (pb.stash ? 0 : pb.NBLK * pb.NBLK * 256) + pb.NBLK * pb.JB * 256;
         double gvx = small[tid];
-        if (tid < pb.Do) gvx += small_b[tid];
-        double gvy = small[16 + tid];
-        if (tid < a.dim_y) gvy += a.tail[3 + tid];
+        if (a.ngp > 1) {
+            const GpTail& pb = a.gp[1];
+            const double* small_b = pb.slab + 2 * pb.NBLK * 256 + (pb.stash ? 0 : pb.NBLK * pb.NBLK * 256) + pb.NBLK * pb.JB * 256;
+            if (tid < pb.Do) gvx += small_b[tid];
+        }
         a.g_vx[tid] = gvx * sigmoid(a.vx_unc[tid]);
-        a.g_vy[tid] = gvy * sigmoid(a.vy_unc[tid]);
+        if (tid < a.n_vy) {
+            double gvy = small[16 + tid];
+            if (tid < a.dim_y) gvy += a.tail[3 + tid];
+            a.g_vy[tid] = gvy * sigmoid(a.vy_unc[tid]);
+        }
     }
 }
 
@@ -335,6 +419,16 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
                           const double* gB_dense_b, int64_t gB_ld, const double* pflat, const double* cflat, double* work,
                           double* gflat, void* stream)
 {
+    return cbfssm_train_tail_g_f64(pl, Lf, pack_f, Lb, pack_b, red, gB_dense_f, gB_dense_b, gB_ld, 0, pflat, cflat, work, gflat,
+                                   stream);
+}
+
+int cbfssm_train_tail_g_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layout* Lf, const double* pack_f,
+                            const cbfssm_pack_layout* Lb, const double* pack_b, const double* red, const double* gB_dense_f,
+                            const double* gB_dense_b, int64_t gB_ld, int g_mode, const double* pflat, const double* cflat,
+                            double* work, double* gflat, void* stream)
+{
+    if (g_mode < 0 || g_mode > 2) return fail(-1, "g_mode must be 0, 1 or 2");
     if (!pl || !Lf || !Lb || !pack_f || !pack_b || !red || !pflat || !cflat || !work || !gflat)
         return fail(-1, "null pointer");
     if (Lf->M != pl->M || Lb->M != pl->M || Lf->D != pl->D || Lb->D != pl->D) return fail(-1, "layouts disagree");
@@ -366,7 +460,10 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
         p.g_z = gflat + off[0]; p.g_mu = gflat + off[1]; p.g_s2 = gflat + off[2]; p.g_var = gflat + off[3];
         p.g_ls = gflat + off[4];
         p.M = M; p.D = L[g]->D; p.Do = L[g]->Do; p.NBLK = L[g]->NBLK; p.JB = L[g]->JB; p.stash = L[g]->rev_stash;
+        p.gmode = g_mode;
+        p.Kkl = nullptr; p.T2 = nullptr; p.shared_ls = 0;
     }
+    a.ngp = 2; a.n_vy = pl->dim_x;
     a.tail = slab;
     a.vx_unc = pflat + pl->off[10]; a.vy_unc = pflat + pl->off[11];
     a.g_vx = gflat + pl->off[10]; a.g_vy = gflat + pl->off[11];
@@ -379,6 +476,59 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
     hipLaunchKernelGGL(tail_finish, dim3(2), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail(-int(e) - 1000, "train tail launch failed");
+}
+
+int64_t cbfssm_train_tail_half_work_elems(const cbfssm_pack_layout* L)
+{
+    if (!L) return -1;
+    return int64_t(L->M) * (L->M > 48 ? L->M : 48) + 2 * int64_t(L->M) * L->M + (int64_t(L->M) + 63) / 64 * 64;
+}
+
+int cbfssm_train_tail_half_f64(const cbfssm_pack_layout* L, const double* pack, const double* pack_kl, int shared_ls,
+                               const double* red, const double* gB_dense, int64_t gB_ld, int dim_y, const double* pflat,
+                               const double* cflat, double* work, double* gflat, void* stream)
+{
+    if (!L || !pack || !red || !pflat || !cflat || !work || !gflat) return fail(-1, "null pointer");
+    if (L->rev_slab <= 0) return fail(-3, "no adjoint slab for M=%d", L->M);
+    if (L->M > 320 || L->D > 32) return fail(-3, "tail kernel limits: M <= 320, D <= 32");
+    if ((L->rev_stash != 0) != (gB_dense != nullptr)) return fail(-1, "the dense K^-1 adjoint is required exactly in stash mode");
+    if (dim_y < 1 || dim_y > L->Do) return fail(-1, "bad dim_y");
+    TailArgs a;
+    memset(&a, 0, sizeof(a));
+    GpTail& p = a.gp[0];
+    const int M = L->M, D = L->D, Do = L->Do;
+    p.slab = red;
+    p.gB_dense = gB_dense; p.gB_ld = gB_ld;
+    p.Kinv = pack + L->Kinv; p.Kmm = pack + L->Kmm; p.Zs = pack + L->Zs;
+    double* w = work;
+    p.T = w; w += int64_t(M) * (M > 48 ? M : 48);
+    p.G2 = w; w += int64_t(M) * M;
+    p.T2 = w; w += int64_t(M) * M;
+    p.dv = w;
+    p.scal = pack + L->scal;
+    p.Kkl = pack_kl ? pack_kl + L->Kinv : nullptr;
+    p.shared_ls = shared_ls ? 1 : 0;
+    // flat layout: zeta_pos [M][D] | zeta_mean [M][Do] | zeta_var(_unc) [M][Do] | variance(_unc) [1] | lengthscales(_unc)
+    // [D or 1] | var_x(_unc) [Do] | var_y(_unc) [dim_y]
+    const int64_t o1 = int64_t(M) * D, o2 = o1 + int64_t(M) * Do, o3 = o2 + int64_t(M) * Do, o4 = o3 + 1,
+                  o5 = o4 + (shared_ls ? 1 : D), o6 = o5 + Do;
+    p.zmean = cflat + o1; p.zvar = cflat + o2; p.var = cflat + o3; p.ls = cflat + o4;
+    p.zvar_unc = pflat + o2; p.var_unc = pflat + o3; p.ls_unc = pflat + o4;
+    p.g_z = gflat; p.g_mu = gflat + o1; p.g_s2 = gflat + o2; p.g_var = gflat + o3; p.g_ls = gflat + o4;
+    p.M = M; p.D = D; p.Do = Do; p.NBLK = L->NBLK; p.JB = L->JB; p.stash = L->rev_stash; p.gmode = 0;
+    a.tail = red + L->rev_slab;
+    a.vx_unc = pflat + o5; a.vy_unc = pflat + o6;
+    a.g_vx = gflat + o5; a.g_vy = gflat + o6;
+    a.dim_x = Do; a.dim_y = dim_y; a.ngp = 1; a.n_vy = dim_y;
+    const unsigned nb = unsigned((M + 15) / 16);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tail_gemm<0>, dim3(nb, nb, 1), dim3(16, 16), 0, st, a);
+    if (pack_kl) hipLaunchKernelGGL(tail_gemm<3>, dim3(nb, nb, 1), dim3(16, 16), 0, st, a);
+    hipLaunchKernelGGL(tail_gemm<1>, dim3(nb, nb, 1), dim3(16, 16), 0, st, a);
+    hipLaunchKernelGGL(tail_gemm<2>, dim3(3, nb, 1), dim3(16, 16), 0, st, a);
+    hipLaunchKernelGGL(tail_finish, dim3(1), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail(-int(e) - 1000, "train tail (forward-only variant) launch failed");
 }
 
 int cbfssm_data_tail_f64(const cbfssm_problem* p, const double* var_y, const double* ll_part, const double* out8, double cL,

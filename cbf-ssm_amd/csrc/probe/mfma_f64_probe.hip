@@ -37,6 +37,23 @@ __global__ void mfma_rate_kernel(double* out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// float32 matrix instruction of the float32-arithmetic path (cbfssm_f32.hip, cbfssm_rev32.hip): v_mfma_f32_16x16x4_f32
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ void mfma32_rate_kernel(double* out, int iters)
+{
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+    f4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = f4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int NACC>
 __global__ void fma_rate_kernel(double* out, int iters)
 {
@@ -131,6 +148,15 @@ int main()
         auto cyc = [&](float ms, int nacc) { double wps = wpc / 4.0; return ms * 1e-3 * clk / (double(iters) * nacc * wps); };
         printf("MFMA f64 16x16x4  waves/CU %2d: 1acc %.1f TF (%.1f cyc/mfma/simd@nominal) 2acc %.1f TF (%.1f) 4acc %.1f TF (%.1f)\n",
                wpc, tf(m1, 1), cyc(m1, 1), tf(m2, 2), cyc(m2, 2), tf(m4, 4), cyc(m4, 4));
+    }
+    for (int wpc : {4, 8, 16}) {
+        int blocks = cus * wpc;
+        float m2 = time_ms([&] { mfma32_rate_kernel<2><<<blocks, 64>>>(dout, iters); });
+        float m4 = time_ms([&] { mfma32_rate_kernel<4><<<blocks, 64>>>(dout, iters); });
+        auto tf = [&](float ms, int nacc) { return 2048.0 * nacc * iters * blocks / (ms * 1e-3) / 1e12; };
+        auto cyc = [&](float ms, int nacc) { double wps = wpc / 4.0; return ms * 1e-3 * clk / (double(iters) * nacc * wps); };
+        printf("MFMA f32 16x16x4  waves/CU %2d: 2acc %.1f TF (%.1f cyc/mfma/simd@nominal) 4acc %.1f TF (%.1f)\n",
+               wpc, tf(m2, 2), cyc(m2, 2), tf(m4, 4), cyc(m4, 4));
     }
     for (int wpc : {4, 8, 16}) {
         int blocks = cus * wpc;

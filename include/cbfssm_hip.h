@@ -297,9 +297,12 @@ int cbfssm_reduce_partials_f64(double* gpart, int64_t slab, int64_t nwg, double*
 /*
  * Stash mode (layout->rev_stash, M > 112): the `*_bwd_ex_f64` launches write, per (workgroup, step) slot, the two MFMA
  * operand images of  d loss / d K^-1 += A2bar K^T  (stash_a: A2bar^T, stash_k: K^T; [slot][NBLK][4][64] doubles each, i.e.
- * 16 NBLK x stash_ld doubles per buffer with stash_ld = 16 x slots).  This contracts `nslots` slots and ADDS the result to
- * ginv_image, an MFMA C-layout image [NBLK][NBLK][4][64] (the layout of the in-register variant's slab section; row =
- * 16 rb + (lane >> 4) + 4 r, column = 16 cb + (lane & 15)).  work: cbfssm_stash_contract_work_elems doubles.
+ * 16 NBLK x stash_ld doubles per buffer with stash_ld = 16 x slots).  This contracts `nslots` slots and ADDS the SYMMETRIC
+ * PART of the result, (B + B^T) / 2 with B = sum A2bar K^T, to ginv_image, an MFMA C-layout image [NBLK][NBLK][4][64] (the
+ * layout of the in-register variant's slab section; row = 16 rb + (lane >> 4) + 4 r, column = 16 cb + (lane & 15)).  The
+ * symmetric part is all the train tail uses (d loss / d K_mm = -K^-1 (.) K^-1 contracted with a symmetric dK_mm/dtheta), and
+ * it halves the accumulator: the kernel holds the lower-triangular blocks of A2bar K^T + K A2bar^T only (cbfssm_contract.hip).
+ * CBFSSM_CONTRACT_FULL=1 (measurement switch) adds B itself.  work: cbfssm_stash_contract_work_elems doubles.
  */
 int64_t cbfssm_stash_contract_work_elems(const cbfssm_pack_layout* layout, int64_t nslots);
 int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* stash_a, const double* stash_k, int64_t nslots,
@@ -333,10 +336,11 @@ int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* st
  * Cholesky -> K^-1 adjoint stays float64, as the reference keeps the Cholesky in float64, gp_tf.py:57-65) take them, with ONE
  * difference: the matrix section holds G = sum (K^-1 A2bar) A2^T = K^-1 (d loss / d K^-1) K^-1, the data part of the K_mm
  * adjoint itself (a float32 accumulator of d loss / d K^-1 would have its rounding multiplied by K^-1 from both sides in the
- * tail).  The tail expects d loss / d K^-1: replace the section by K G K, K = K_mm + jitter I (pack sections Kmm, scal), two
- * M x M float64 products -- cbf-ssm_amd/cbfssm/hip/train.py:_adjoint_f32.  For tile heights above 112 rows hand that
- * section to cbfssm_train_tail_f64 as gB_dense_* with gB_ld = 0.
- * Above 208 inducing points one call launches two passes over the time loop (half of the columns of G each).
+ * tail).  cbfssm_train_tail_g_f64 takes the section as it is: g_mode = 1 for tile heights up to 10 row blocks (the full
+ * matrix G), g_mode = 2 from 13 row blocks (M > 160: two row blocks per wave) -- there the kernel accumulates only the
+ * lower-triangular 16 x 16 blocks of S = C A2^T + A2 C^T, C = K^-1 A2bar (diagonal blocks: C A2^T; blocks above the diagonal
+ * are never written), the symmetric part (S + S^T) / 2 of G being all that d loss / d K_mm uses: one pass over the time loop at
+ * every tile height.  For tile heights above 112 rows hand that section to the tail as gB_dense_* with gB_ld = 0.
  */
 int64_t cbfssm_pack_f32_elems(const cbfssm_pack_layout* layout);
 int cbfssm_gp_pack_f32(const cbfssm_pack_layout* layout, const double* pack, float* pack32, void* stream);
@@ -393,6 +397,28 @@ int cbfssm_train_tail_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layou
                           const cbfssm_pack_layout* layout_b, const double* pack_b, const double* red,
                           const double* gB_dense_f, const double* gB_dense_b, int64_t gB_ld, const double* pflat,
                           const double* cflat, double* work, double* gflat, void* stream);
+/* The same with the matrix section in another form (what the float32 adjoint leaves, cbfssm_*_pass_bwd_f32):
+ * g_mode 0: d loss / d K^-1 (= cbfssm_train_tail_f64); 1: G = K^-1 (d loss / d K^-1) K^-1, the data part of d loss / d K_mm
+ * itself, as a full matrix; 2: the lower-triangular 16 x 16 blocks of G + G^T (diagonal blocks: of G), blocks above the
+ * diagonal ignored.  Only the symmetric part of G enters (dK_mm/dtheta is symmetric, gp_tf.py:33-49). */
+int cbfssm_train_tail_g_f64(const cbfssm_param_layout* pl, const cbfssm_pack_layout* layout_f, const double* pack_f,
+                            const cbfssm_pack_layout* layout_b, const double* pack_b, const double* red,
+                            const double* gB_dense_f, const double* gB_dense_b, int64_t gB_ld, int g_mode, const double* pflat,
+                            const double* cflat, double* work, double* gflat, void* stream);
+
+/*
+ * The same tail for the forward-only variants -- CBFSSMHALF (cbfssmhalf.py:20-47,174-199) and the PR-SSM baseline
+ * (prssm.py:28-47,81-82,96): ONE GP (gp_f), var_y with dim_y entries.  Flat vectors (pflat unconstrained, cflat constrained,
+ * gflat the gradient) in the order zeta_pos [M][D] | zeta_mean [M][Do] | zeta_var [M][Do] | variance [1] | lengthscales [D, or
+ * 1 with shared_ls: PR-SSM's one lengthscale for all input dimensions, prssm.py:40] | var_x [Do] | var_y [dim_y].
+ * red = [slab | loglik, kl_x, entropy (0), dloss/dvar_y[dim_y]] (cbfssm_reduce_partials_f64 + cbfssm_data_tail_f64).
+ * pack_kl: NULL, or (PR-SSM) the pack of the same parameters prepared with jitter 0 -- the prior-KL terms then use the
+ * jitter-free K_mm^-1 as the reference factorises the prior without jitter.  work: cbfssm_train_tail_half_work_elems doubles.
+ */
+int64_t cbfssm_train_tail_half_work_elems(const cbfssm_pack_layout* layout);
+int cbfssm_train_tail_half_f64(const cbfssm_pack_layout* layout, const double* pack, const double* pack_kl, int shared_ls,
+                               const double* red, const double* gB_dense, int64_t gB_ld, int dim_y, const double* pflat,
+                               const double* cflat, double* work, double* gflat, void* stream);
 
 /* The rank-local data terms of the flat reduce buffer: tail[0..2] = loglik, kl_x, entropy (from the ELBO combination's
  * out[0..2]); tail[3 + d] = d loss / d var_y[d] through the log-likelihood (cbfssm.py:245-251), d < dim_y, from the

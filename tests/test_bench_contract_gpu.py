@@ -39,3 +39,25 @@ def test_bench_line_has_the_contract_keys(mode):
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in cpu, k
     assert cpu['kind'] == 'port' and cpu['value'] > 0 and cpu['cores'] >= 1
+
+
+def test_float32_bench_line_has_a_roof():
+    """`--dtype float32` (the reference's model dtype argument): the float32 kernels timed like the float64 ones, against the
+    float32 matrix peak."""
+    rec = _run('--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'C1', '--mode', 'train', '--dtype', 'float32',
+               '--no-cpu-baseline')
+    roof = rec['roofline']
+    assert rec['dtype'] == 'f32' and roof['bound'] == 'mfma' and roof['peak'] == pytest.approx(157.3)
+    assert roof['frac'] == pytest.approx(roof['achieved'] / roof['peak']) and roof['achieved'] > 0
+    assert set(roof['kernel_ms']) == {'backward_pass_f32', 'forward_pass_f32', 'forward_pass_adjoint_f32',
+                                      'backward_pass_adjoint_f32'}
+
+
+@pytest.mark.parametrize('model', ['half', 'prssm'])
+def test_variant_bench_lines(model):
+    """`--model half|prssm`: the forward-only variants have a bench line with a roof."""
+    rec = _run('--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'C1', '--model', model)
+    assert rec['config']['model'] == model and rec['config']['mode'] == 'train' and rec['value'] > 0
+    roof = rec['roofline']
+    assert roof['bound'] == 'mfma' and roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'])
+    assert set(roof['kernel_ms']) == {'forward_pass', 'forward_pass_adjoint'}
