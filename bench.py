@@ -163,7 +163,7 @@ def bench_variant(args, dev):
     shape.  A step = recognition model, K_mm / Cholesky / K^-1 + packing, the forward pass, log-likelihood + moments, and for
     mode=train the adjoint pass, the K_mm adjoint + prior KL and the TF-1.8 Adam update."""
     from cbfssm import synthetic as syn
-    from cbfssm.hip.train_half import HipHalfGrad
+    from cbfssm.hip.train_half import HipHalfGrad, HipHalfTrainStep
     from cbfssm.hip.train import TFAdam
     from cbfssm.hip import ops
     w = syn.WORKLOADS[args.workload or 'C3']
@@ -177,13 +177,12 @@ def bench_variant(args, dev):
     opt = TFAdam({k: torch.tensor(v, device=dev) for k, v in p_np.items()}, cfg['learning_rate'])
     params = opt.views
     noise_pipe = ops.NoisePipeline(dev, g, with_backward=False)
+    stepper = HipHalfTrainStep(eng, opt)                  # one HIP-graph replay per train step (CBFSSM_HIP_GRAPH=0: eager)
 
     def step():
         noise = noise_pipe.next(w.T, w.N)
         if mode == 'train':
-            loss, grads, _ = eng.loss_and_grads(params, u, y, noise, True)
-            opt.step(grads)
-            return loss
+            return stepper.step(u, y, noise, True)
         return eng.forward(params, u, y, noise, True)[0]
 
     for _ in range(args.warmup):
@@ -199,6 +198,7 @@ def bench_variant(args, dev):
 
     # ---- the time-loop kernels by themselves: every launch of a step bracketed by HIP events (eng._prof)
     ms, n = {}, {}
+    stepper.use_graph = False                             # (eager launches, each bracketed by events)
     for _ in range(3):
         eng._prof = []
         step()
@@ -653,7 +653,7 @@ def main():
         # (profiles/tools/collect_traffic.sh) are committed per round; the newest file that has the entry is quoted and
         # named in `traffic_source`
         traffic, traffic_source = None, None
-        for rnd in ('r03', 'r02', 'r01'):
+        for rnd in ('r04', 'r03', 'r02', 'r01'):
             tpath = os.path.join(ROOT, 'profiles', rnd, 'traffic.json')
             if os.path.exists(tpath):
                 val = json.load(open(tpath)).get('%s:%s' % (args.workload, mode), {}).get(name)

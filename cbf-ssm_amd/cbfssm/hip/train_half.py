@@ -365,3 +365,64 @@ class HipHalfGrad:
         grads['var_x_unc'] = small[0:self.dim_x] * torch.sigmoid(p['var_x_unc'])
         grads['var_y_unc'] = (small[16:16 + self.dim_y] + tail[3:]) * torch.sigmoid(p['var_y_unc'])
         return loss, grads, terms
+
+
+class HipHalfTrainStep:
+    """One `sess.run((model.train, model.loss))` of a forward-only variant (training/trainer.py:40) as ONE HIP-graph replay:
+    the recognition model forward and its autograd backward (GRU(16) over recog_len steps: a few hundred tiny launches, most
+    of an eager step at the small-scale shapes), K_mm / Cholesky / K^-1, the pass, its adjoint, the train tail and the Adam
+    update.  One graph per (shapes, condition, GP form), captured at first use; single device (a data-parallel run keeps
+    eager launches around its collective)."""
+
+    def __init__(self, engine, opt, graph=None):
+        self.engine, self.opt = engine, opt
+        if graph is None:
+            graph = engine.config.get('hip_graph', os.environ.get('CBFSSM_HIP_GRAPH', '1') != '0')
+        self.use_graph = bool(graph) and engine.dist is None
+        self._graphs = {}
+        self.last_terms = self.last_ws = None
+
+    def _eager(self, u, y, noise, condition, **kw):
+        loss, grads, terms = self.engine.loss_and_grads(self.opt.views, u, y, noise, condition, **kw)
+        self.opt.step(grads)
+        self.last_terms, self.last_ws = terms, self.engine.last_ws
+        return loss
+
+    def step(self, u, y, noise, condition=True, **kw):
+        eng = self.engine
+        if not self.use_graph or kw:
+            return self._eager(u, y, noise, condition, **kw)
+        dev = eng.device
+        u, y, eps = _f64(u, dev), _f64(y, dev), _f64(noise['eps_f'], dev)
+        # (auto form: a completed condition-number read-back may flip the GP form -- other kernels, another graph)
+        forms = tuple(pk.update_form() for pk in (eng.pack_f, eng.pack_kl) if pk is not None)
+        key = (tuple(u.shape), tuple(y.shape), bool(condition), forms)
+        g = self._graphs.get(key)
+        if g is None:
+            g = {'u': u.clone(), 'y': y.clone(), 'noise': {'eps_f': eps.clone()}}
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):                 # warm-up outside the capture (workspaces, autograd state); no update
+                for _ in range(2):
+                    eng.loss_and_grads(self.opt.views, g['u'], g['y'], g['noise'], condition)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss, grads, terms = eng.loss_and_grads(self.opt.views, g['u'], g['y'], g['noise'], condition)
+                if getattr(grads, 'flat', None) is not None:
+                    self.opt.step(grads)
+                else:
+                    self.opt.step_device(grads)
+                self.opt._t -= 1                          # capture does not execute; every replay counts below
+            g.update(graph=graph, loss=loss, terms=terms, ws=eng.last_ws)
+            self._graphs[key] = g
+        else:
+            g['u'].copy_(u)
+            g['y'].copy_(y)
+            g['noise']['eps_f'].copy_(eps)
+        g['graph'].replay()
+        self.opt._t += 1
+        self.last_terms, self.last_ws = g['terms'], g['ws']
+        return g['loss'].clone()

@@ -178,13 +178,17 @@ class CBFSSM(BaseModel):
         return u, y
 
     def _train_stepper(self):
-        """HipTrainStep over this model's engine and optimiser (CBFSSM only: the variants' recognition networks run in
-        the tensor library's autograd, outside the captured launches)."""
+        """The HIP-graph stepper over this model's engine and optimiser: HipTrainStep for CBFSSM, HipHalfTrainStep for the
+        forward-only variants (their recognition network's autograd launches are captured too)."""
         from ..hip.train import HipElboGrad, HipTrainStep
-        if type(self._engine) is not HipElboGrad:
-            return None
+        from ..hip.train_half import HipHalfGrad, HipHalfTrainStep
         if getattr(self, '_stepper', None) is None or self._stepper.engine is not self._engine:
-            self._stepper = HipTrainStep(self.config, None, self._device, self._dist, engine=self._engine, opt=self._opt)
+            if type(self._engine) is HipElboGrad:
+                self._stepper = HipTrainStep(self.config, None, self._device, self._dist, engine=self._engine, opt=self._opt)
+            elif type(self._engine) is HipHalfGrad:
+                self._stepper = HipHalfTrainStep(self._engine, self._opt)
+            else:
+                return None
         return self._stepper if self._stepper.use_graph else None
 
     def _draw_noise(self, B, T, common=False):

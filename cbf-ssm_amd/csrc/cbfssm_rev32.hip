@@ -306,8 +306,34 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
             if (i < 16 * naux) xb[(Do + (i >> 4)) * PD + (i & 15)] = float(av[k2]) * auxl[k2];
         }
     };
+    // inputs of phase D of step t: {eps, y~ (fwd) or the y2 adjoint (bwd), fmean, fvar}.  Issued a phase early (at the top of
+    // phase F, under its matrix loop) -- loaded where they are used they put two dependent HBM / L2 round trips on the serial
+    // chain of every step (the float64 kernel's epilogue_load, cbfssm_adjoint.hpp).
+    auto epilogue_load = [&](int t, int tm, float& eps_t, float (&yin)[QPW], float (&fm)[QPW], float (&fv)[QPW]) {
+        eps_t = 0.0f;
+        if (MODE == MODE_FWD) eps_t = float(a.eps[int64_t(t) * N + c]);
+        else eps_t = float(a.eps[(int64_t(run) * T + t) * N + c]);
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int d = 4 * g + (w + qi * W);
+            yin[qi] = 0.0f; fm[qi] = 0.0f; fv[qi] = 1.0f;
+            if (act[qi]) {
+                const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+                const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
+                fm[qi] = float(o[0]); fv[qi] = float(o[1]);
+                if (MODE == MODE_FWD) {
+                    yin[qi] = (d < a.dim_y) ? float(a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d])
+                                            : float(a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)]);
+                } else {
+                    const bool write = (run == 0) ? (tm < R) : (tm >= R);
+                    if (write) yin[qi] = float(a.gy2[(int64_t(t) * N + c) * Do + d]);
+                }
+            }
+        }
+    };
     // phase D of step t: adjoint of the step epilogue (cbfssm.py:145-156, 205-235) from the carried state adjoint
-    auto epilogue_adjoint = [&](int t, int tm) {
+    auto epilogue_adjoint = [&](int t, int tm, const float eps_t, const float (&yin)[QPW], const float (&fmi)[QPW],
+                                const float (&fvi)[QPW]) {
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             const int q = w + qi * W;
@@ -315,16 +341,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                 const int d = 4 * g + q;
                 float gfm = 0.0f, gfv = 0.0f;
                 if (act[qi] && cvalid) {
-                    const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
-                    const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
-                    const float fmean = float(o[0]), fvar = float(o[1]);
+                    const float fmean = fmi[qi], fvar = fvi[qi];
                     const float gout = gcar[qi];
                     if (MODE == MODE_FWD) {
-                        const float eps_t = float(a.eps[int64_t(t) * N + c]);
                         const bool do_cond = (a.condition || (t < R - 1));                          // cbfssm.py:227
                         if (do_cond) {
-                            const float ytil = (d < a.dim_y) ? float(a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d])
-                                                             : float(a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)]);
+                            const float ytil = yin[qi];
                             const float kf1 = a.k_factor - 1.0f;
                             const float vyt = vy[qi] + kf1 * fvar;
                             const float s = vyt + fvar;
@@ -361,10 +383,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                         }
                     } else {
                         // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
-                        const float eps_t = float(a.eps[(int64_t(run) * T + t) * N + c]);
                         const bool write = (run == 0) ? (tm < R) : (tm >= R);
-                        const float gy2in = write ? float(a.gy2[(int64_t(t) * N + c) * Do + d]) : 0.0f;
-                        const float gtot = gout + gy2in;
+                        const float gtot = gout + yin[qi];                      // (the y2 adjoint: zero on unwritten steps)
                         gfm = gtot;
                         gfv = gtot * eps_t * 0.5f * rsqrt32(fvar) - (write ? a.cE * 0.5f * rcp32(fvar) : 0.0f);
                     }
@@ -382,7 +402,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         double av[AUXR];
         load_inputs(t_of(0), tmod, hcur, av);
         store_inputs(xq0, hcur, av);
-        epilogue_adjoint(t_of(0), tmod);
+        float e0, y0[QPW], m0[QPW], v0[QPW];
+        epilogue_load(t_of(0), tmod, e0, y0, m0, v0);
+        epilogue_adjoint(t_of(0), tmod, e0, y0, m0, v0);
     }
     __syncthreads();
 
@@ -556,6 +578,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         __syncthreads();                                                                           // 4
 
         // ---- F: Kbar = K^-1 A2bar - A2 o colsum(Fv), Ebar = Kbar o K, input adjoint partials, Zbar~
+        // (phase D inputs of the next step and this step's observation for phase G: issued here, consumed after barrier 5)
+        float eps_n = 0.0f, yin_n[QPW], fm_n[QPW], fv_n[QPW], ycur[QPW];
+        if (has_next) epilogue_load(tn, tmn, eps_n, yin_n, fm_n, fv_n);
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int d = 4 * g + (w + qi * W);
+            ycur[qi] = 0.0f;
+            if (MODE == MODE_FWD && act[qi] && d < a.dim_y && t >= 1) ycur[qi] = float(a.y[(int64_t(bq) * T + t) * a.dim_y + d]);
+        }
         f4 ebar[RB];
         {
             f4 kb_[RB];
@@ -693,8 +724,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                                 const int d = 4 * g + q;
                                 if (act[qi] && cvalid) {
                                     if (t >= 1 && d < a.dim_y) {
-                                        const float ycur = float(a.y[(int64_t(bq) * T + t) * a.dim_y + d]);
-                                        gin += -a.cL * (ycur - hcur[qi]) * ivy[qi];      // log-likelihood term of x_t
+                                        gin += -a.cL * (ycur[qi] - hcur[qi]) * ivy[qi];  // log-likelihood term of x_t
                                     }
                                     if (first && t == 0 && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = double(gin);
                                 }
@@ -709,7 +739,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         }
         // ---- D of the next step: same lanes as the carried adjoint just produced
         if (has_next) {
-            epilogue_adjoint(tn, tmn);
+            epilogue_adjoint(tn, tmn, eps_n, yin_n, fm_n, fv_n);
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) hcur[qi] = hnext[qi];
         }

@@ -23,7 +23,7 @@ for f in glob.glob(path + '/**/*counter_collection.csv', recursive=True):
         acc[key][row['Counter_Name']].append(float(row['Counter_Value']))
 print('workload', wl)
 for (name, grid, wg), d in sorted(acc.items(), key=lambda kv: -sum(kv[1].get('SQ_BUSY_CYCLES', [0]))):
-    if not any(t in name for t in ('pass_kernel', 'rev_kernel')):
+    if not any(t in name for t in ('pass_kernel', 'rev_kernel', 'stash_contract')):
         continue
     m = {c: sum(v) / len(v) for c, v in d.items()}
     n = len(next(iter(d.values())))
