@@ -22,7 +22,7 @@ SYMBOLS = (
     'cbfssm_backward_pass_bwd_f64', 'cbfssm_reduce_partials_f64', 'cbfssm_gp_prepare2_f64', 'cbfssm_bwd_segments', 'cbfssm_forward_pass_bwd_ex_f64',
     'cbfssm_backward_pass_bwd_ex_f64', 'cbfssm_half_forward_pass_f64', 'cbfssm_half_forward_pass_bwd_f64',
     'cbfssm_saved_a2_elems', 'cbfssm_param_layout_init', 'cbfssm_constrain_f64', 'cbfssm_train_tail_work_elems',
-    'cbfssm_train_tail_f64', 'cbfssm_train_tail_g_f64', 'cbfssm_train_tail_half_work_elems', 'cbfssm_train_tail_half_f64', 'cbfssm_adam_step_f64', 'cbfssm_loglik_partials', 'cbfssm_data_tail_f64', 'cbfssm_stash_contract_work_elems', 'cbfssm_stash_contract_f64',
+    'cbfssm_train_tail_f64', 'cbfssm_train_tail_g_f64', 'cbfssm_train_tail_half_work_elems', 'cbfssm_train_tail_half_f64', 'cbfssm_gru_recog_param_elems', 'cbfssm_gru_recog_act_elems', 'cbfssm_gru_recog_f64', 'cbfssm_gru_recog_bwd_f64', 'cbfssm_adam_step_f64', 'cbfssm_loglik_partials', 'cbfssm_data_tail_f64', 'cbfssm_stash_contract_work_elems', 'cbfssm_stash_contract_f64',
     'cbfssm_cholesky_f64', 'cbfssm_rbf_k_f64', 'cbfssm_gp_predict_fullq_work_elems', 'cbfssm_gp_predict_fullq_f64',
     'cbfssm_pack_f32_elems', 'cbfssm_gp_pack_f32', 'cbfssm_gp_pack_bf16', 'cbfssm_gp_predict_f32', 'cbfssm_backward_pass_f32', 'cbfssm_forward_pass_f32',
     'cbfssm_rev32_slab_elems', 'cbfssm_forward_pass_bwd_f32', 'cbfssm_backward_pass_bwd_f32',
@@ -91,6 +91,12 @@ def load():
     lib.cbfssm_train_tail_half_work_elems.restype = i64
     lib.cbfssm_train_tail_half_work_elems.argtypes = [C.POINTER(PackLayout)]
     lib.cbfssm_train_tail_half_f64.argtypes = [C.POINTER(PackLayout), vp, vp, ip, vp, vp, i64, ip, vp, vp, vp, vp, vp]
+    lib.cbfssm_gru_recog_param_elems.restype = i64
+    lib.cbfssm_gru_recog_param_elems.argtypes = [ip, ip, ip]
+    lib.cbfssm_gru_recog_act_elems.restype = i64
+    lib.cbfssm_gru_recog_act_elems.argtypes = [ip, ip]
+    lib.cbfssm_gru_recog_f64.argtypes = [ip, ip, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp]
+    lib.cbfssm_gru_recog_bwd_f64.argtypes = [ip, ip, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, vp]
     lib.cbfssm_stash_contract_work_elems.restype = i64
     lib.cbfssm_stash_contract_work_elems.argtypes = [C.POINTER(PackLayout), i64]
     lib.cbfssm_stash_contract_f64.argtypes = [C.POINTER(PackLayout), vp, vp, i64, vp, vp, vp]

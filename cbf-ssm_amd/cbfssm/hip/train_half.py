@@ -101,6 +101,10 @@ class HipHalfGrad:
         self.fused_tail = self.slab_f > 0 and not os.environ.get('CBFSSM_TORCH_TAIL')
         self.gp_names = self.names[:7]                       # the five GP tensors, var_x_unc, var_y_unc: the tail's flat order
         self.tail_work = None
+        # the GRU recognition model as two launches (cbfssm_gru_recog[_bwd]_f64: one wave per sequence) instead of ~800 tensor-
+        # library launches through autograd; CBFSSM_TORCH_GRU=1 keeps the latter (same numbers, a cross-check)
+        self.fused_gru = self.rnn and not os.environ.get('CBFSSM_TORCH_GRU')
+        self._gru = {}
 
     def _timed(self, kind, fn):
         """measurement hook (bench.py --model half|prssm): with a list in self._prof the launch is bracketed by HIP events"""
@@ -131,7 +135,34 @@ class HipHalfGrad:
             return gru_recognition(rp, u, y, self.config['recog_len'])
         return conv_recognition(rp, u, y, self.config['recog_len'])
 
-    def _x0(self, p, u, y):
+    def _recog_flat(self, params, p):
+        """the six recognition tensors as one flat vector: the tail of the optimiser's own storage when `params` are its views"""
+        flat = getattr(params, 'flat', None)
+        n = sum(p[k].numel() for k in RECOG_NAMES)
+        if flat is not None and flat.device == self.device and tuple(params.keys())[-6:] == RECOG_NAMES:
+            return flat[flat.numel() - n:]
+        return torch.cat([p[k].reshape(-1) for k in RECOG_NAMES])
+
+    def _gru_forward(self, rflat, u, y, keep):
+        lib = _l.load()
+        B, T = u.shape[0], u.shape[1]
+        R = min(int(self.config['recog_len']), T)            # (the window is the first recog_len steps: all of a shorter sequence)
+        f = dict(dtype=torch.float64, device=self.device)
+        key = (B, R)
+        if key not in self._gru:
+            P = int(lib.cbfssm_gru_recog_param_elems(self.dim_u, self.dim_y, self.dim_x))
+            self._gru[key] = {'x0': torch.zeros(B, self.dim_x, **f), 'P': P,
+                              'act': torch.zeros(int(lib.cbfssm_gru_recog_act_elems(B, R)), **f),
+                              'gpart': torch.zeros((B + 32) * P, **f)}
+        g = self._gru[key]
+        rc = lib.cbfssm_gru_recog_f64(B, T, self.dim_u, self.dim_y, self.dim_x, R, _ptr(u), _ptr(y), _ptr(rflat), _ptr(g['x0']),
+                                      _ptr(g['act']) if keep else None, _stream())
+        _l.check(rc, 'cbfssm_gru_recog_f64')
+        return g
+
+    def _x0(self, p, u, y, params=None):
+        if self.fused_gru:
+            return self._gru_forward(self._recog_flat(params, p), u, y, keep=False)['x0']
         if self.rnn or self.conv:
             return self._recog(p, u, y)
         B = u.shape[0]
@@ -219,7 +250,7 @@ class HipHalfGrad:
         prob = self._problem(u.shape[0], u.shape[1], condition)
         ws = self._workspace(prob)
         with torch.no_grad():
-            x0 = self._x0(p, u, y).contiguous()
+            x0 = self._x0(p, u, y, params).contiguous()
         self._forward(p, self._constrained(p), x0, u, y, _f64(noise['eps_f'], dev), prob, ws)
         self.last_ws = ws
         red2 = None
@@ -244,7 +275,12 @@ class HipHalfGrad:
         eps_f = _f64(noise['eps_f'], dev)
         rp = {}
         rnames = self._recog_params(p)
-        if rnames:
+        gru = None
+        if self.fused_gru:
+            rflat = self._recog_flat(params, p)
+            gru = self._gru_forward(rflat, u, y, keep=True)
+            x0 = gru['x0']
+        elif rnames:
             rp = {k: p[k].detach().clone().requires_grad_(True) for k in rnames}
             x0g = self._recog(rp, u, y)
             x0 = x0g.detach().contiguous()
@@ -305,7 +341,18 @@ class HipHalfGrad:
                  'cbfssm_data_tail_f64')
         gx0_b = ws.gx0.view(B, self.S, self.dim_x).sum(1)        # d loss / d x_0 per sequence (tiled over S, :87)
         rgrads = {}
-        if rnames:
+        if gru is not None:
+            P = gru['P']
+            rc = lib.cbfssm_gru_recog_bwd_f64(B, T, self.dim_u, self.dim_y, self.dim_x, min(int(self.config['recog_len']), T), _ptr(u),
+                                              _ptr(y), _ptr(rflat), _ptr(gru['act']), _ptr(gx0_b.contiguous()), _ptr(gru['gpart']), st)
+            _l.check(rc, 'cbfssm_gru_recog_bwd_f64')
+            rg = torch.zeros(P, dtype=torch.float64, device=dev)
+            _l.check(lib.cbfssm_reduce_partials_f64(_ptr(gru['gpart']), P, B, _ptr(rg), st), 'reduce recog')
+            o = 0
+            for k in rnames:
+                rgrads[k] = rg[o:o + p[k].numel()].view(p[k].shape)
+                o += p[k].numel()
+        elif rnames:
             gl = torch.autograd.grad(x0g, [rp[k] for k in rnames], grad_outputs=gx0_b)
             rgrads = dict(zip(rnames, gl))
         if self.dist is not None and not local:

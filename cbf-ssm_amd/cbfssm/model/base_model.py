@@ -3,6 +3,7 @@
 tf.data semantics kept: from_tensor_slices -> repeat(repeats) -> shuffle(buffer) -> batch(batch_size, keep the
 partial last batch) -> one mini-batch per `sess.run` until OutOfRange (base_model.py:24-31,42-69).
 """
+import os
 import sys
 import numpy as np
 
@@ -68,7 +69,32 @@ class BaseModel:
 
     @staticmethod
     def run(sess, tensors, feed_dict, show_progress=False):
-        """base_model.py:42-69: sess.run until the iterator is exhausted, results concatenated on axis 0."""
+        """base_model.py:42-69: sess.run until the iterator is exhausted, results concatenated on axis 0.
+
+        When every fetch is a scalar of the ELBO (train, loss, loglik, ...: what Trainer runs, training/trainer.py:40,46) the
+        mini-batches of the pass are issued back to back and their scalars are read from the device ONCE, after the last
+        one: the reference's `sess.run` hands the loss to the host every step, which on the GPU is a stream synchronisation
+        per step with the device idle while the host prepares the next launch.  Same values, same order; a failed Cholesky
+        (InvalidArgumentError) surfaces at the end of the pass instead of at its step."""
+        flist = list(tensors) if isinstance(tensors, (tuple, list)) else [tensors]
+        models = {f.model for f in flist if isinstance(f, Fetch)}
+        model = models.pop() if len(models) == 1 else None
+        names = [f.name for f in flist if isinstance(f, Fetch)]
+        if (model is not None and len(names) == len(flist) and hasattr(model, '_SCALAR_FETCHES') and not show_progress
+                and all(n in model._SCALAR_FETCHES for n in names) and not os.environ.get('CBFSSM_RUN_SYNC')):
+            import torch
+            feed = {(k.name if isinstance(k, Fetch) else k): v for k, v in (feed_dict or {}).items()}
+            rows = []
+            while True:
+                try:
+                    rows.append(model._execute(sess, names, feed, lazy=True))
+                except OutOfRangeError:
+                    break
+            if not rows:
+                return None
+            host = torch.stack(rows).cpu().numpy()                   # the pass's one device-to-host transfer
+            per_run = [model._scalar_results(names, h) for h in host]
+            return [np.asarray([r[i] for r in per_run]) if n != 'train' else None for i, n in enumerate(names)]
         res_all = None
         while True:
             try:

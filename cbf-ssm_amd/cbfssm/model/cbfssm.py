@@ -147,9 +147,11 @@ class CBFSSM(BaseModel):
             pins = self._pins = {}
         key = (data_in.shape, data_out.shape)
         if key not in pins:
-            pins[key] = [[torch.empty(s, dtype=torch.float64).pin_memory() for s in key] for _ in range(2)] + [0]
+            pins[key] = [[torch.empty(s, dtype=torch.float64).pin_memory() for s in key] + [None] for _ in range(2)] + [0]
         slot = pins[key][pins[key][2]]
         pins[key][2] ^= 1
+        if slot[2] is not None:
+            slot[2].synchronize()         # this slot's previous upload (two batches ago; BaseModel.run lets the host run ahead)
         slot[0].numpy()[...] = data_in
         slot[1].numpy()[...] = data_out
         with torch.cuda.stream(self._upload):                       # not behind the kernels of the running step
@@ -157,6 +159,7 @@ class CBFSSM(BaseModel):
             y = slot[1].to(self._device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._upload)
+        slot[2] = ev
         return u, y, ev
 
     def _stage_ahead(self):
@@ -235,7 +238,11 @@ class CBFSSM(BaseModel):
     _SHARDED_FETCHES = frozenset(('train', 'loss', 'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b'))
 
     # ---- one sess.run
-    def _execute(self, sess, names, feed):
+    _SCALAR_FETCHES = ('train', 'loss', 'loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b')
+
+    def _execute(self, sess, names, feed, lazy=False):
+        """One `sess.run`.  lazy (BaseModel.run, scalar fetches only): returns the device row [info, loss, scalars...] instead
+        of host values -- the caller reads all rows of a pass over the data back at once, so that no step waits for the host."""
         self._ensure(sess)
         if names == ['init']:
             for k, v in self._init_values.items():
@@ -284,8 +291,17 @@ class CBFSSM(BaseModel):
         # one device-to-host transfer for everything scalar that this run fetches (each .item() is a stream sync)
         scal_names = [k for k in ('loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b') if k in names]
         dev0 = dict(dtype=torch.float64, device=self._device)
-        host = torch.stack([torch.as_tensor(v, **dev0).reshape(())
-                            for v in [terms['info'], loss] + [terms[k] for k in scal_names]]).cpu().numpy()
+        row = torch.stack([torch.as_tensor(v, **dev0).reshape(())
+                           for v in [terms['info'], loss] + [terms[k] for k in scal_names]])
+        if lazy:
+            assert all(n in self._SCALAR_FETCHES for n in names)
+            return row
+        host = row.cpu().numpy()
+        return self._scalar_results(names, host, ws, y, B, T)
+
+    def _scalar_results(self, names, host, ws=None, y=None, B=None, T=None):
+        """host = [info, loss, scalars in _SCALAR_FETCHES order...] of one run -> the fetched values"""
+        scal_names = [k for k in ('loglik', 'kl_x', 'entropy', 'kl_z_f', 'kl_z_b') if k in names]
         info, loss_h = float(host[0]), float(host[1])
         scal_h = {k: float(host[2 + i]) for i, k in enumerate(scal_names)}
         if info != 0.0:

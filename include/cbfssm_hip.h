@@ -420,6 +420,23 @@ int cbfssm_train_tail_half_f64(const cbfssm_pack_layout* layout, const double* p
                                const double* red, const double* gB_dense, int64_t gB_ld, int dim_y, const double* pflat,
                                const double* cflat, double* work, double* gflat, void* stream);
 
+/*
+ * Recognition model of the forward-only variants: x_0 = dense(GRUCell(16)(the first recog_len steps of [u, y], reversed))
+ * (cbfssm/model/cbfssmhalf.py:82-93, cbfssm/model/prssm.py:132-141; TF-1.8 GRUCell gate layout).  params: the six tensors
+ * behind each other -- gate kernel [dim_u + dim_y + 16][32], gate bias [32], candidate kernel [dim_u + dim_y + 16][16],
+ * candidate bias [16], dense kernel [16][dim_x], dense bias [dim_x] = cbfssm_gru_recog_param_elems doubles.  One wave per
+ * sequence; act (cbfssm_gru_recog_act_elems doubles, or NULL when no gradient follows) keeps every step's h, r, u, c.
+ * The backward call takes d loss / d x_0 per sequence (the adjoint pass's gx0 summed over the particles) and writes one
+ * gradient slab of cbfssm_gru_recog_param_elems doubles per sequence (gpart: room for B + CBFSSM_REDUCE_SPLIT slabs);
+ * cbfssm_reduce_partials_f64(gpart, elems, B, out) sums them in a fixed order.
+ */
+int64_t cbfssm_gru_recog_param_elems(int dim_u, int dim_y, int dim_x);
+int64_t cbfssm_gru_recog_act_elems(int B, int recog_len);
+int cbfssm_gru_recog_f64(int B, int T, int dim_u, int dim_y, int dim_x, int recog_len, const double* u, const double* y,
+                         const double* params, double* x0, double* act, void* stream);
+int cbfssm_gru_recog_bwd_f64(int B, int T, int dim_u, int dim_y, int dim_x, int recog_len, const double* u, const double* y,
+                             const double* params, const double* act, const double* gx0, double* gpart, void* stream);
+
 /* The rank-local data terms of the flat reduce buffer: tail[0..2] = loglik, kl_x, entropy (from the ELBO combination's
  * out[0..2]); tail[3 + d] = d loss / d var_y[d] through the log-likelihood (cbfssm.py:245-251), d < dim_y, from the
  * per-dimension totals of ll_part (cbfssm_loglik_moments_f64).  cL = loss_factors[0] / S. */

@@ -105,3 +105,44 @@ def test_batched_test_experiments_equal_the_reference_loop(monkeypatch):
     for a, b in zip(res['loop'][0], res['batched'][0]):
         assert np.asarray(a).shape == np.asarray(b).shape and np.array_equal(np.asarray(a), np.asarray(b))
     assert res['loop'][1] == res['batched'][1]
+
+
+def test_pipelined_pass_equals_the_per_step_loop(monkeypatch):
+    """`model.run` over scalar fetches issues the mini-batches of a pass back to back and reads their losses once
+    (base_model.py:42-69 hands every loss to the host, a stream synchronisation per step): the same model and seed trained
+    both ways gives bitwise the same per-batch losses, test losses and parameters, incl. a ragged last batch."""
+    from cbfssm.datasets import make_synthetic_ds
+    from cbfssm.model import CBFSSM
+    from cbfssm.model.session import Session
+
+    ds_sel = make_synthetic_ds(dim_u=1, dim_y=1, n_train=400, n_test=160, seed=1)
+    dim_x = 3
+    cfg = {'ds': ds_sel, 'batch_size': 7, 'shuffle': 100, 'seed': 11, 'dim_x': dim_x, 'ind_pnt_num': 20, 'samples': 10,
+           'learning_rate': 0.05, 'loss_factors': np.asarray([1., 0.]), 'k_factor': 5., 'recog_len': 8, 'zeta_pos': 2.,
+           'zeta_mean': 0.05 ** 2, 'zeta_var': 0.01 ** 2, 'var_x': np.asarray([0.002 ** 2] * dim_x),
+           'var_y': np.asarray([1. ** 2] * dim_x), 'gp_var': 0.5 ** 2, 'gp_len': 2.}
+    ds = ds_sel(40, 20)
+    res = {}
+    for mode in ('sync', 'pipelined'):
+        if mode == 'sync':
+            monkeypatch.setenv('CBFSSM_RUN_SYNC', '1')
+        else:
+            monkeypatch.delenv('CBFSSM_RUN_SYNC', raising=False)
+        np.random.seed(321)
+        m = CBFSSM(dict(cfg))
+        with m.graph.as_default(), Session() as sess:
+            sess.run(m.init)
+            tr, te = [], []
+            for _ in range(2):
+                m.load_ds(sess, ds.train_in_batch, ds.train_out_batch)
+                out = m.run(sess, (m.train, m.loss), {m.condition: True})
+                assert out[0] is None
+                tr.append(out[1])
+                m.load_ds(sess, ds.test_in_batch, ds.test_out_batch)
+                te.append(m.run(sess, m.loss, {m.condition: True})[0])
+            pars = {k: sess.run(v) for k, v in m.var_dict.items()}
+        res[mode] = (np.concatenate(tr), np.concatenate(te), pars)
+    assert res['sync'][0].shape == res['pipelined'][0].shape and res['sync'][0].size > 2
+    assert np.array_equal(res['sync'][0], res['pipelined'][0]) and np.array_equal(res['sync'][1], res['pipelined'][1])
+    for k in res['sync'][2]:
+        assert np.array_equal(res['sync'][2][k], res['pipelined'][2][k]), k
