@@ -53,7 +53,7 @@ class PRSSM(CBFSSM):
             raise NotImplementedError('PRSSM computes in float64 (float32 arithmetic is built for CBFSSM)')
         return HipHalfGrad(self.config, sess.device, dist, variant='prssm'), half_param_names(self.config, 'prssm')
 
-    def _execute(self, sess, names, feed):
+    def _execute(self, sess, names, feed, lazy=False):
         feed = dict(feed)
         feed.setdefault('condition', False)      # the PR-SSM graph has no use for the placeholder (prssm.py:19-130)
-        return super()._execute(sess, names, feed)
+        return super()._execute(sess, names, feed, lazy=lazy)
