@@ -637,6 +637,11 @@ __global__ void loglik_moments_kernel(LlArgs a)
     }
 }
 
+// (Measured and NOT kept, round 4: a wave per (t, b) span -- fully coalesced 512-byte wave loads of the S dim_x contiguous
+// doubles, parked in an LDS strip, lanes d < dim_x reducing over the particles, the next span's loads in registers meanwhile:
+// 42.5 us against 38.0 us at C3, 327 against 205 us at C5, 37 against 10 us at C2 on a buffer rotation larger than the
+// Infinity Cache.  The 112-byte stride of the form above costs partial lines at L1, not HBM efficiency; what the span form
+// loses is bytes in flight -- 14 reducing lanes per wave behind an LDS round trip.)
 struct CombineArgs {
     const double* ll; int64_t n_ll;
     const double* kl; int64_t n_kl;
@@ -1184,8 +1189,8 @@ int cbfssm_loglik_moments_f64(const cbfssm_problem* p, const double* var_y, cons
     a.var_y = var_y; a.y = y; a.x = x; a.ll_part = ll_part; a.pred_mean = pred_mean; a.pred_var = pred_var;
     a.int_mean = int_mean; a.int_var = int_var;
     const int64_t total = int64_t(p->B) * p->T * p->dim_x;
-    hipLaunchKernelGGL(loglik_moments_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    const int64_t nblk = (total + 255) / 256;
+    hipLaunchKernelGGL(loglik_moments_kernel, dim3(unsigned(nblk)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("loglik_moments");
 }
 
