@@ -484,27 +484,29 @@ def main():
         kern = {
             'backward_pass_f32': (time32(lambda: lib.check(l.cbfssm_backward_pass_f32(
                 C.byref(prob), lb_, b32b, P(var_x), P(u), P(y), P(noise['hid_b']), P(noise['eps_b']), P(ws.y2), P(ws.h_all),
-                P(ws.fmv_b), P(ws.ent_part), st), 'bwd32'), reps), pts_b * F(w.M, w.D, w.dim_out_b)),
+                P(ws.fmv_b), P(ws.a2s_b), P(ws.ent_part), st), 'bwd32'), reps), pts_b * F(w.M, w.D, w.dim_out_b)),
             'forward_pass_f32': (time32(lambda: lib.check(l.cbfssm_forward_pass_f32(
                 C.byref(prob), lf_, b32f, P(var_x), P(var_y), P(u), P(y), P(ws.y2), P(noise['eps_f']), P(ws.x), P(ws.fmv_f),
-                P(ws.kl_part), st), 'fwd32'), reps), pts_f * F(w.M, w.D, w.dim_x))}
+                P(ws.a2s_f), P(ws.kl_part), st), 'fwd32'), reps), pts_f * F(w.M, w.D, w.dim_x))}
         if mode == 'train':
             cL, cE = float(cfg['loss_factors'][0]) / w.S, float(cfg['loss_factors'][1]) / w.S
-            # (the float32 adjoint keeps no tiles: it recomputes the kernel tile and A2 -- 3 F per GP evaluation)
+            # with the tiles the passes kept the reverse sweep costs 2 F per GP evaluation (K^-1 A2bar and the accumulation),
+            # 3 F when it recomputes the kernel tile and A2
+            fa32 = 2.0 if ws.a2s_b is not None else 3.0
             kern['forward_pass_adjoint_f32'] = (time32(lambda: lib.check(l.cbfssm_forward_pass_bwd_f32(
-                C.byref(prob), lf_, b32f, P(var_x), P(var_y), P(u), P(y), P(ws.y2), P(noise['eps_f']), P(ws.x), P(ws.fmv_f), cL,
-                P(ws.gy2), P(ws.gpart_f), st), 'rev fwd32'), max(1, reps // 2)), 3.0 * pts_f * F(w.M, w.D, w.dim_x))
+                C.byref(prob), lf_, b32f, P(var_x), P(var_y), P(u), P(y), P(ws.y2), P(noise['eps_f']), P(ws.x), P(ws.fmv_f),
+                P(ws.a2s_f), cL, P(ws.gy2), P(ws.gpart_f), st), 'rev fwd32'), max(1, reps // 2)), fa32 * pts_f * F(w.M, w.D, w.dim_x))
             kern['backward_pass_adjoint_f32'] = (time32(lambda: lib.check(l.cbfssm_backward_pass_bwd_f32(
                 C.byref(prob), lb_, b32b, P(var_x), P(u), P(y), P(noise['hid_b']), P(noise['eps_b']), P(ws.h_all), P(ws.fmv_b),
-                P(ws.gy2), cE, P(ws.gpart_b), st), 'rev bwd32'), max(1, reps // 2)), 3.0 * pts_b * F(w.M, w.D, w.dim_out_b))
+                P(ws.a2s_b), P(ws.gy2), cE, P(ws.gpart_b), st), 'rev bwd32'), max(1, reps // 2)), fa32 * pts_b * F(w.M, w.D, w.dim_out_b))
         name = max(kern, key=lambda k: kern[k][0])
         ach = kern[name][1] / kern[name][0] / 1e12
         roof = {'bound': 'mfma', 'achieved': ach, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / F32_MFMA_PEAK_TFLOPS, 'traffic': None, 'kernel': name,
                 'kernel_ms': {k: v[0] * 1e3 for k, v in kern.items()},
                 'kernel_tflops': {k: v[1] / v[0] / 1e12 for k, v in kern.items()},
-                'note': 'float32 arithmetic (v_mfma_f32_16x16x4_f32, 32 cycles per SIMD: 157.3 TFLOP/s); full launches; the '
-                        'adjoint recomputes the kernel tile and A2 and is priced at 3 F per GP evaluation'}
+                'note': 'float32 arithmetic (v_mfma_f32_16x16x4_f32, 32 cycles per SIMD: 157.3 TFLOP/s); full launches; the adjoint is '
+                        'priced at 2 F per GP evaluation when it reads the kept [A2 | kernel tile] records, 3 F when it recomputes them'}
     elif rank == 0:
         import ctypes as C
         l = lib.load()

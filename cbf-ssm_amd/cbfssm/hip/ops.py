@@ -360,11 +360,11 @@ def elbo_forward(prob, pack_f, pack_b, var_x, var_y, u, y, hid_b, eps_b, eps_f, 
         b32, f32p = pack_b.pack_f32(bf16), pack_f.pack_f32(bf16)
         rc = lib.cbfssm_backward_pass_f32(pb, C.byref(pack_b.layout), C.c_void_p(b32.data_ptr()), _ptr(var_x), _ptr(u),
                                           _ptr(y), _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.fmv_b),
-                                          _ptr(ws.ent_part), st)
+                                          _ptr(ws.a2s_b), _ptr(ws.ent_part), st)
         _l.check(rc, 'cbfssm_backward_pass_f32')
         rc = lib.cbfssm_forward_pass_f32(pb, C.byref(pack_f.layout), C.c_void_p(f32p.data_ptr()), _ptr(var_x), _ptr(var_y),
                                          _ptr(u), _ptr(y), _ptr(ws.y2), _ptr(eps_f) if eps_f.numel() else None,
-                                         _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.kl_part), st)
+                                         _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st)
         _l.check(rc, 'cbfssm_forward_pass_f32')
         return _elbo_tail(lib, pb, prob, pack_f, pack_b, var_y, y, loss_factors, ws, st)
     rc = lib.cbfssm_backward_pass_f64(pb, C.byref(pack_b.layout), _ptr(pack_b.buf), _ptr(var_x), _ptr(u), _ptr(y),

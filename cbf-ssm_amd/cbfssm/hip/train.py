@@ -224,6 +224,14 @@ class HipElboGrad:
             f = dict(dtype=torch.float64, device=self.device)
             ws.gy2 = torch.zeros_like(ws.y2)
             if self.f32:
+                # every step's [A2 | kernel tile] registers of the float32 passes, float32: the adjoint reads them back instead
+                # of recomputing both (cbfssm_rev32.hip, KSV); same pool and budget as the float64 tiles, None above it
+                if not os.environ.get('CBFSSM_F32_NO_TILES'):
+                    na_f = (int(lib.cbfssm_saved_a2_f32_elems(C.byref(prob), C.byref(self.pack_f.layout), 0)) + 1) // 2
+                    na_b = (int(lib.cbfssm_saved_a2_f32_elems(C.byref(prob), C.byref(self.pack_b.layout), 1)) + 1) // 2
+                    assert na_f >= 0 and na_b > 0, 'record count'
+                    reserve = 8.0 * prob.T * prob.B * prob.S * (3 * prob.dim_x + 8 * self.dob) + 2.0 * 2 ** 30
+                    ws.a2s_f, ws.a2s_b = self.tile_pool.get(max(na_f, 1), na_b, reserve)
                 ws.gpart_f = torch.zeros((n_f + 32) * self.slab32_f, **f)
                 ws.gpart_b = torch.zeros((n_b + 32) * self.slab32_b, **f)
                 ws.n_f, ws.n_b = n_f, n_b
@@ -430,7 +438,7 @@ class HipElboGrad:
             if self.f32:
                 _l.check(lib.cbfssm_backward_pass_f32(C.byref(q), lb, b32b, _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b),
                                                       _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all), _ptr(ws.fmv_b),
-                                                      _ptr(ws.ent_part), st), 'cbfssm_backward_pass_f32')
+                                                      _ptr(ws.a2s_b), _ptr(ws.ent_part), st), 'cbfssm_backward_pass_f32')
                 return
             _l.check(lib.cbfssm_backward_pass_f64(C.byref(q), lb, _ptr(self.pack_b.buf), _ptr(c['var_x']), _ptr(u), _ptr(y),
                                                   _ptr(hid_b), _ptr(eps_b), _ptr(ws.y2), _ptr(ws.h_all),
@@ -440,7 +448,8 @@ class HipElboGrad:
         def fwd(q, st):
             if self.f32:
                 _l.check(lib.cbfssm_forward_pass_f32(C.byref(q), lf_, b32f, _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y),
-                                                     _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.kl_part), st),
+                                                     _ptr(ws.y2), e_eps, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f),
+                                                     _ptr(ws.kl_part), st),
                          'cbfssm_forward_pass_f32')
                 return
             _l.check(lib.cbfssm_forward_pass_f64(C.byref(q), lf_, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']),
@@ -510,13 +519,13 @@ class HipElboGrad:
         def rfwd(q, stq):
             _l.check(lib.cbfssm_forward_pass_bwd_f32(C.byref(q), C.byref(self.pack_f.layout), C.c_void_p(b32f.data_ptr()),
                                                      _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(ws.y2), e_eps,
-                                                     _ptr(ws.x), _ptr(ws.fmv_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), stq),
+                                                     _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gy2), _ptr(ws.gpart_f), stq),
                      'cbfssm_forward_pass_bwd_f32')
 
         def rbwd(q, stq):
             _l.check(lib.cbfssm_backward_pass_bwd_f32(C.byref(q), C.byref(self.pack_b.layout), C.c_void_p(b32b.data_ptr()),
                                                       _ptr(c['var_x']), _ptr(u), _ptr(y), _ptr(hid_b), _ptr(eps_b),
-                                                      _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), stq),
+                                                      _ptr(ws.h_all), _ptr(ws.fmv_b), _ptr(ws.a2s_b), _ptr(ws.gy2), cE, _ptr(ws.gpart_b), stq),
                      'cbfssm_backward_pass_bwd_f32')
         if split is None:
             rfwd(prob, st)

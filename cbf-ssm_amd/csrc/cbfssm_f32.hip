@@ -79,6 +79,9 @@ struct Args32 {
     double* x_out;
     double* part_out;
     double* fmv;          // optional: (fmean, fvar) of every step, kept for the adjoint (PassArgs::fmv layout)
+    float* a2s;           // optional: every step's [A2 | kernel tile] accumulator registers, [slot][group][2][NBLK][4][64] floats
+                          // (slot = t, or run T + t for the backward runs): the float32 adjoint reads them instead of
+                          // recomputing both (cbfssm_rev32.hip, KSV)
     double* h_all;        // optional (backward runs): every step's output of both runs
     int tri;              // 1: two-triangular GP form (layout->gp_form == CBFSSM_GP_FORM_TRI)
     int group0;           // chain-group split: this launch covers the 16-chain groups [group0, group0 + gridDim.x)
@@ -141,7 +144,7 @@ struct Tile32 {
     // that keeps fvar_0 meaningful on an ill-conditioned K_mm: a sum of squares instead of sigma^2 - k.(K^-1 k), whose two
     // terms agree to cond eps_32.
     template <bool TRI>
-    __device__ __forceinline__ void gp(const float* xq, float* Kt, float* At, float* part, int w, int l)
+    __device__ __forceinline__ void gp(const float* xq, float* Kt, float* At, float* part, int w, int l, float* rec = nullptr)
     {
         float bx[DK], xx = 0.0f;
 #pragma unroll
@@ -253,6 +256,13 @@ struct Tile32 {
             const int rb = w * RB + i;
             if (rb < NBLK) {
                 const f4 a2 = acc[i][0] + acc[i][1];
+                if (rec) {                                  // kept for the adjoint: the registers as they are (row 4 g + r)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        rec[(rb * 4 + r) * 64 + l] = a2[r];
+                        rec[NBLK * 256 + (rb * 4 + r) * 64 + l] = kreg[i][r];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     P1 = CBF_MFMA32(mu[(rb * 4 + r) * 64 + l], a2[r], P1);
@@ -467,7 +477,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
 #pragma unroll
         for (int k2 = 0; k2 < AUXR; ++k2) auxr[k2] = has_next ? aux_load(k2, tn) : 0.0;
 
-        tile.template gp<TRI>(xq, Kt, At, part, w, l);    // (one workgroup barrier inside, two in the two-triangular form)
+        float* rec = nullptr;
+        if (a.a2s) {
+            const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+            rec = a.a2s + (slot * G16 + gx) * (2 * NBLK * 256);
+        }
+        tile.template gp<TRI>(xq, Kt, At, part, w, l, rec);    // (one workgroup barrier inside, two in the two-triangular form)
         __syncthreads();                                  // part complete; xq and Kt free
 
 #pragma unroll
@@ -666,16 +681,25 @@ int cbfssm_gp_predict_f32(const cbfssm_pack_layout* L, const float* pack32, cons
     return rc ? fail(rc, "gp_predict_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;
 }
 
+int64_t cbfssm_saved_a2_f32_elems(const cbfssm_problem* p, const cbfssm_pack_layout* L, int backward_runs)
+{
+    if (!p || !L) return -1;
+    const int64_t groups = (int64_t(p->B) * p->S + 15) / 16;
+    const int64_t slots = backward_runs ? 2 * int64_t(p->T) : (p->T > 1 ? int64_t(p->T) - 1 : 0);
+    return slots * groups * 2 * L->NBLK * 256;            // [A2 | kernel tile] accumulator registers of every step and group
+}
+
 int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_b,
                              const double* var_x, const double* u, const double* y, const double* hid_b,
-                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* ent_part, void* stream)
+                             const double* eps_b, double* y2, double* h_all, double* fmv_b, float* a2s_b, double* ent_part,
+                             void* stream)
 {
     Args32 a;
     int rc = fill32(a, p, L, pack32_b, p ? p->dim_x - p->dim_y : 0);
     if (rc) return rc;
     if (!var_x || !u || !y || !hid_b || !eps_b || !y2 || !ent_part) return fail(-1, "null pointer");
     a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.y2_out = y2; a.part_out = ent_part;
-    a.h_all = h_all; a.fmv = fmv_b;
+    a.h_all = h_all; a.fmv = fmv_b; a.a2s = a2s_b;
     const int P = 2 * p->recog_len;
     const int n0 = p->T / P + 1, n1 = (p->T + p->recog_len) / P + 1;       // as cbfssm_backward_pass_f64 counts them
     a.nseg0 = n0;
@@ -686,7 +710,8 @@ int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* 
 
 int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
-                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* kl_part, void* stream)
+                            const double* y2, const double* eps_f, double* x, double* fmv_f, float* a2s_f, double* kl_part,
+                            void* stream)
 {
     Args32 a;
     int rc = fill32(a, p, L, pack32_f, p ? p->dim_x : 0);
@@ -694,7 +719,7 @@ int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L
     if (!var_x || !var_y || !u || !y || !x || !kl_part || (p->dim_x > p->dim_y && !y2) || (p->T > 1 && !eps_f))
         return fail(-1, "null pointer");
     a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x; a.part_out = kl_part;
-    a.fmv = fmv_f;
+    a.fmv = fmv_f; a.a2s = a2s_f;
     dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 1);
     rc = dispatch32(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
     return rc ? fail(rc, "forward_pass_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;

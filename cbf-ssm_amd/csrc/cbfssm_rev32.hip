@@ -44,6 +44,7 @@ struct Rev32Args {
     const double* y2;
     const double* h_all;
     const double* fmv;
+    const float* a2s;      // optional: every step's [A2 | kernel tile] registers as kept by the float32 passes (Args32::a2s)
     double* gy2;
     double* gpart;
     int64_t slab;
@@ -119,7 +120,10 @@ __device__ __forceinline__ void symg_zero(f4 (&gS)[N])
 // W (.) then W^T (.) with W = L^-1, the way the reference back-substitutes twice (gp_tf.py:137,145) -- the zero blocks are
 // skipped, the intermediate rows travel through one more LDS tile and one more workgroup barrier per product.  In float32
 // the explicit K^-1 loses cond eps_32 in each of these products; the triangular factors lose sqrt(cond) eps_32.
-template <int NBLK, int RB, int DK, int MODE, int NCB, bool TRI>
+// KSV: the forward evaluation kept every step's A2 and kernel tile (Rev32Args::a2s): phases B and C -- 6 MFMAs and four
+// exponentials, then the whole K^-1 K product per row block -- become two loads issued a step ahead, the barrier between
+// them goes, and the Z~ rows / row constants / K^-1 rows of the wave are not held.
+template <int NBLK, int RB, int DK, int MODE, int NCB, bool TRI, bool KSV = false>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev32Args a)
 {
     constexpr int W = (NBLK + RB - 1) / RB, NT = 64 * W, MP = 16 * NBLK, KS = MP / 4;
@@ -178,12 +182,14 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
     const int rb_lo = rbs[0], rb_hi = ok[RB - 1] ? rbs[RB - 1] : rbs[0];      // (two-triangular products: the k-block ranges)
     // Z~ rows and row constants of the owned row blocks (kernel tile, gp_tf.py:33-49)
     float Zreg[RB][DK], czr[RB][4];
+    if constexpr (!KSV) {
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
+        for (int i = 0; i < RB; ++i) {
 #pragma unroll
-        for (int s = 0; s < DK; ++s) Zreg[i][s] = a.pk.Zp[(rbs[i] * DK + s) * 64 + l];
+            for (int s = 0; s < DK; ++s) Zreg[i][s] = a.pk.Zp[(rbs[i] * DK + s) * 64 + l];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) czr[i][r] = a.pk.cz[16 * rbs[i] + 4 * g + r];
+            for (int r = 0; r < 4; ++r) czr[i][r] = a.pk.cz[16 * rbs[i] + 4 * g + r];
+        }
     }
     // M <= 112 (one row block per wave), dense form: the K^-1 rows of the wave in VGPRs for the whole pass
     constexpr bool BREG = (NBLK <= 7 && RB == 1 && !TRI);
@@ -397,7 +403,28 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         }
     };
 
+    // KSV: the kept [A2 | kernel tile] registers of this wave's row blocks for the NEXT step, issued behind barrier 5
+    const int64_t G16 = (int64_t(N) + 15) >> 4;
+    f4 a2n[KSV ? RB : 1], kn[KSV ? RB : 1];
+    auto load_saved = [&](int t) {
+        if constexpr (KSV) {
+            const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
+            const float* rp = a.a2s + (slot * G16 + gx) * (2 * NBLK * 256) + l;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                a2n[i] = f4{0, 0, 0, 0}; kn[i] = f4{0, 0, 0, 0};
+                if (ok[i]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a2n[i][r] = rp[(rbs[i] * 4 + r) * 64];
+                        kn[i][r] = rp[NBLK * 256 + (rbs[i] * 4 + r) * 64];
+                    }
+                }
+            }
+        }
+    };
     float hcur[QPW];
+    if (nsteps > 0) load_saved(t_of(0));
     if (nsteps > 0) {
         double av[AUXR];
         load_inputs(t_of(0), tmod, hcur, av);
@@ -422,7 +449,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         double auxn[AUXR];
         if (has_next) load_inputs(tn, tmn, hnext, auxn);
 
-        // ---- B: kernel tile rows of this wave -> LDS
+        // ---- B: kernel tile rows of this wave -> LDS  (KSV: kept by the forward evaluation, loaded a step ahead)
+        f4 kreg[RB], a2[RB];
+        if constexpr (!KSV) {
         float bx[DK], xx = 0.0f;
 #pragma unroll
         for (int s = 0; s < DK; ++s) {
@@ -431,7 +460,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         }
         xx += __shfl_xor(xx, 16);
         xx += __shfl_xor(xx, 32);
-        f4 kreg[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             kreg[i] = f4{0, 0, 0, 0};
@@ -449,6 +477,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
             }
         }
         __syncthreads();                                                                           // 1
+        }
 
         // rows of this wave of K^-1 X for the 16-column tile X in LDS ([row m][17]); the operand images stream from L2 in
         // natural k order.  TRI: W X -> At (own rows), barrier, W^T At
@@ -523,8 +552,12 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         };
 
         // ---- C: A2 = K^-1 K, rows of this wave
-        f4 a2[RB];
-        kinv_times(Kt, a2);
+        if constexpr (KSV) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) { kreg[i] = kn[i]; a2[i] = a2n[i]; }
+        } else {
+            kinv_times(Kt, a2);
+        }
 
         // ---- E: A2bar and the parameter adjoints that contract over the 16 chains
         float fvsum = 0.0f, fmB[4], fvB[4], fmT[4], fvT[4];
@@ -676,6 +709,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
             }
         }
         __syncthreads();                                                                           // 5
+        if (has_next) load_saved(tn);                  // (KSV) a2 / kreg were last read in phase F
         // SYMG: S += C A2^T + A2 C^T on this wave's block rows, both tiles complete and untouched until the next step's
         // phase E / F -- in the shadow of phases G / D, which are vector latency on the first waves
         if constexpr (SYMG) {
@@ -826,17 +860,18 @@ static int launch_rev32(int mode, const Rev32Args& a, dim3 grid, hipStream_t st)
     constexpr int NCB = (RB == 2) ? 1 : rev32_ncb(NBLK);        // (RB == 2: the symmetric accumulator, see the kernel)
     const size_t lds = size_t(2 * 4 * DK * 17 + ((TRI ? 4 : 3) + (RB == 2 ? 1 : 0)) * 16 * NBLK * 17 + 2 * 16 * 17 + W * PSL) * sizeof(float);
     hipError_t e = hipSuccess;
+    auto go = [&](auto k) {
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e == hipSuccess) hipLaunchKernelGGL(k, grid, dim3(64 * W), lds, st, a);
+    };
     if (mode == MODE_FWD) {
-        auto k = rev32_kernel<NBLK, RB, DK, MODE_FWD, NCB, TRI>;
-        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return -int(e) - 1000;
-        hipLaunchKernelGGL(k, grid, dim3(64 * W), lds, st, a);
+        if (a.a2s) go(rev32_kernel<NBLK, RB, DK, MODE_FWD, NCB, TRI, true>);
+        else go(rev32_kernel<NBLK, RB, DK, MODE_FWD, NCB, TRI, false>);
     } else {
-        auto k = rev32_kernel<NBLK, RB, DK, MODE_BWD, NCB, TRI>;
-        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return -int(e) - 1000;
-        hipLaunchKernelGGL(k, grid, dim3(64 * W), lds, st, a);
+        if (a.a2s) go(rev32_kernel<NBLK, RB, DK, MODE_BWD, NCB, TRI, true>);
+        else go(rev32_kernel<NBLK, RB, DK, MODE_BWD, NCB, TRI, false>);
     }
+    if (e != hipSuccess) return -int(e) - 1000;
     e = hipGetLastError();
     return e == hipSuccess ? 0 : -int(e) - 1000;
 }
@@ -917,8 +952,8 @@ int64_t cbfssm_rev32_slab_elems(const cbfssm_pack_layout* L)
 
 int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
                                 const double* var_x, const double* var_y, const double* u, const double* y,
-                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, double cL,
-                                double* gy2, double* gpart, void* stream)
+                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, const float* a2s_f,
+                                double cL, double* gy2, double* gpart, void* stream)
 {
     Rev32Args a;
     int rc = fill_rev32(a, p, L, pack32_f, p ? p->dim_x : 0);
@@ -927,7 +962,7 @@ int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layou
         (p->dim_x > p->dim_y && (!y2 || !gy2)))
         return fail(-1, "null pointer");
     a.cL = float(cL); a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.x = x; a.y2 = y2; a.gy2 = gy2;
-    a.gpart = gpart; a.fmv = fmv_f;
+    a.gpart = gpart; a.fmv = fmv_f; a.a2s = a2s_f;
     const int ncb = rev32_ncb(L->NBLK);
     dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 1, 1);
     for (int cb0 = 0; cb0 < L->NBLK; cb0 += ncb) {
@@ -940,15 +975,15 @@ int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layou
 
 int cbfssm_backward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_b,
                                  const double* var_x, const double* u, const double* y, const double* hid_b,
-                                 const double* eps_b, const double* h_all, const double* fmv_b, const double* gy2, double cE,
-                                 double* gpart, void* stream)
+                                 const double* eps_b, const double* h_all, const double* fmv_b, const float* a2s_b,
+                                 const double* gy2, double cE, double* gpart, void* stream)
 {
     Rev32Args a;
     int rc = fill_rev32(a, p, L, pack32_b, p ? p->dim_x - p->dim_y : 0);
     if (rc) return rc;
     if (!var_x || !u || !y || !hid_b || !eps_b || !h_all || !fmv_b || !gy2 || !gpart) return fail(-1, "null pointer");
     a.cE = float(cE); a.var_x = var_x; a.u = u; a.y = y; a.eps = eps_b; a.hid = hid_b; a.h_all = h_all;
-    a.gy2 = const_cast<double*>(gy2); a.gpart = gpart; a.fmv = fmv_b;
+    a.gy2 = const_cast<double*>(gy2); a.gpart = gpart; a.fmv = fmv_b; a.a2s = a2s_b;
     const int nseg = cbfssm_bwd_segments(p);
     const int nchunk = int(cbfssm_rev_workgroups(p, 1) / (2 * ((int64_t(a.N) + 15) / 16)));      // as the float64 adjoint chunks
     a.seg0 = 0; a.seg1 = nseg; a.nchunk = nchunk < 1 ? 1 : (nchunk > nseg ? nseg : nchunk);

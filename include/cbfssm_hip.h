@@ -330,7 +330,7 @@ int cbfssm_stash_contract_f64(const cbfssm_pack_layout* layout, const double* st
  *
  * float32 ADJOINT (what `minimize` differentiates when the model dtype is float32, cbfssm.py:12,273-275): the reverse
  * sweeps on v_mfma_f32_16x16x4_f32 with float32 accumulation over the time steps; the kernel tile and A2 = K^-1 k are
- * recomputed (no saved tiles).  The partial slabs leave as float64 in the layout of the float64 adjoint for NON-stash tile
+ * read back when the passes kept them (a2s_*), recomputed otherwise.  The partial slabs leave as float64 in the layout of the float64 adjoint for NON-stash tile
  * heights -- [mubar | s2bar | G (NBLK x NBLK C-layout images) | Zbar | small] = cbfssm_rev32_slab_elems doubles per
  * workgroup, cbfssm_rev_workgroups workgroups -- so cbfssm_reduce_partials_f64 and cbfssm_train_tail_f64 (the K_mm ->
  * Cholesky -> K^-1 adjoint stays float64, as the reference keeps the Cholesky in float64, gp_tf.py:57-65) take them, with ONE
@@ -349,19 +349,25 @@ int cbfssm_gp_predict_f32(const cbfssm_pack_layout* layout, const float* pack32,
                           double* fmean, double* fvar, void* stream);
 int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const float* pack32_b,
                              const double* var_x, const double* u, const double* y, const double* hid_b,
-                             const double* eps_b, double* y2, double* h_all, double* fmv_b, double* ent_part, void* stream);
+                             const double* eps_b, double* y2, double* h_all, double* fmv_b, float* a2s_b, double* ent_part,
+                             void* stream);
 int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
-                            const double* y2, const double* eps_f, double* x, double* fmv_f, double* kl_part, void* stream);
+                            const double* y2, const double* eps_f, double* x, double* fmv_f, float* a2s_f, double* kl_part,
+                            void* stream);
+/* a2s_*: NULL, or cbfssm_saved_a2_f32_elems floats -- every step's [A2 | kernel tile] accumulator registers, kept for the float32
+ * adjoint, which then reads them back instead of recomputing the kernel tile and the K^-1 K product (2 F instead of 3 F per GP
+ * evaluation; C3: 3.4 GB for both GPs).  Opaque to the host. */
+int64_t cbfssm_saved_a2_f32_elems(const cbfssm_problem* p, const cbfssm_pack_layout* layout, int backward_runs);
 int64_t cbfssm_rev32_slab_elems(const cbfssm_pack_layout* layout);
 int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
                                 const double* var_x, const double* var_y, const double* u, const double* y,
-                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, double cL,
-                                double* gy2, double* gpart, void* stream);
+                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, const float* a2s_f,
+                                double cL, double* gy2, double* gpart, void* stream);
 int cbfssm_backward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_b, const float* pack32_b,
                                  const double* var_x, const double* u, const double* y, const double* hid_b,
-                                 const double* eps_b, const double* h_all, const double* fmv_b, const double* gy2, double cE,
-                                 double* gpart, void* stream);
+                                 const double* eps_b, const double* h_all, const double* fmv_b, const float* a2s_b,
+                                 const double* gy2, double cE, double* gpart, void* stream);
 
 /*
  * ---- once-per-step tail of a train step ------------------------------------------------------------------------------

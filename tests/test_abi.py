@@ -86,3 +86,19 @@ def test_product_never_imports_the_oracle_and_has_no_fallback(tmp_path, monkeypa
     env = dict(os.environ, CBFSSM_HIP_LIB=str(tmp_path / 'absent.so'))
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=240)
     assert 'LOUD:' in out.stdout and 'no fallback' in out.stdout, (out.stdout, out.stderr)
+
+
+def test_element_counts_come_back_as_64_bit():
+    """Every `*_elems` entry point returns int64_t and the binding says so: at the C5 shape the float32 record buffer of the
+    backward runs has 3.3e10 floats -- a 32-bit result wraps, the buffer is allocated far too small and the passes write
+    outside it (found in round 4: a GPU memory fault above 2^31 floats).  Host arithmetic only: no GPU needed."""
+    l = lib.load()
+    for name in lib.SYMBOLS:
+        if name.endswith('_elems'):
+            assert getattr(l, name).restype is ctypes.c_int64, name
+    prob = lib.make_problem(512, 50, 1000, 4, 2, 2, 300, 50, 1.0, True)
+    lay = lib.pack_layout(300, 6, 2)
+    n32 = l.cbfssm_saved_a2_f32_elems(ctypes.byref(prob), ctypes.byref(lay), 1)
+    assert n32 == 2 * 1000 * 1600 * 2 * 20 * 256 and n32 > 2 ** 31
+    n64 = l.cbfssm_saved_a2_elems(ctypes.byref(prob), ctypes.byref(lay), 1)
+    assert n64 == 2 * 1000 * 1600 * 20 * 256

@@ -217,3 +217,45 @@ def test_precision_sweep_c5_shape_on_the_gpu():
     json.dump(report, open(os.path.join(out, 'precision_sweep_gpu.json'), 'w'), indent=1)
     assert report['initial']['float32']['loss_rel'] <= 1e-4
     assert report['initial']['bfloat16']['loss_rel'] <= 1e-2
+
+
+def test_f32_kept_records_above_2_31_floats():
+    """The float32 passes keep every step's [A2 | kernel tile] registers for the adjoint (cbfssm_saved_a2_f32_elems floats).
+    At M = 300, T = 200, B = 192, S = 50 the backward-run buffer has 2.46e9 floats (9.8 GB): above 2^31 elements, where a
+    32-bit count or offset anywhere between the size query and the kernels is a GPU memory fault (it was one, round 4: the
+    ctypes binding had declared the size query `int`).  Same loss, gradients to float32 rounding, as the recomputing path."""
+    import dataclasses
+    import os
+    from cbfssm.hip.train import HipElboGrad, PARAM_NAMES
+    w = dataclasses.replace(syn.WORKLOADS['C5'], T=200, B=192)
+    cfg = w.model_config()
+    p = {k: torch.tensor(v, device=DEV) for k, v in syn.make_params(w, seed=1).items()}
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    u = torch.randn(w.B, w.T, w.dim_u, dtype=torch.float64, device=DEV, generator=g)
+    y = torch.randn(w.B, w.T, w.dim_y, dtype=torch.float64, device=DEV, generator=g)
+    N, T = w.N, w.T
+    noise = {k: torch.randn(n, dtype=torch.float64, device=DEV, generator=g)
+             for k, n in (('hid_b', 2 * T * N), ('eps_b', 2 * T * N), ('eps_f', (T - 1) * N))}
+    res = {}
+    for mode in ('recompute', 'kept'):
+        if mode == 'recompute':
+            os.environ['CBFSSM_F32_NO_TILES'] = '1'
+        else:
+            os.environ.pop('CBFSSM_F32_NO_TILES', None)
+        try:
+            eng = HipElboGrad(cfg, DEV, dtype='float32')
+            loss, grads, _ = eng.loss_and_grads(p, u, y, noise)
+            torch.cuda.synchronize()
+            assert (eng.last_ws.a2s_b is not None) == (mode == 'kept')
+            if mode == 'kept':
+                assert eng.last_ws.a2s_b.numel() * 2 > 2 ** 31
+            res[mode] = (float(loss), {k: grads[k].clone() for k in PARAM_NAMES})
+        finally:
+            os.environ.pop('CBFSSM_F32_NO_TILES', None)
+        del eng
+        torch.cuda.empty_cache()
+    assert res['kept'][0] == pytest.approx(res['recompute'][0], rel=1e-12)
+    for k in PARAM_NAMES:
+        a, b = res['kept'][1][k], res['recompute'][1][k]
+        assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max()) + 1e-30, k
