@@ -86,7 +86,7 @@ struct Slab {
 // LDS budget of one adjoint workgroup (doubles).  Stash-mode tiles re-read the Z~ operand images every step instead of
 // holding them in registers; when the K^-1 image does not fit anyway, the LDS left over holds those images (a read
 // that misses L1 costs an L2 round trip right in front of the MFMAs that need it).
-template <int NBLK, int RB, int DK, bool STASH, bool KSV = false>
+template <int NBLK, int RB, int DK, bool STASH>
 struct RevLds {
     static constexpr int W = (NBLK + RB - 1) / RB;
     static constexpr int JB = (4 * DK + 1 + 15) / 16;
@@ -103,11 +103,9 @@ struct RevLds {
     static constexpr int ZT = NBLK * JB * 256;                     // (Z~)^T A-operand image
     static constexpr int MU = NBLK * 256;                          // mu_z B-operand image (phase E)
     // filled in this order (measured at NBLK = 13 / D = 21, where only part fits: {(Z~)^T} and {Z~, mu} are within 1 %)
-    // (KSV: the kernel tile is read, not rebuilt -- no Z~ image; the mean image takes its place when it fits)
     static constexpr bool ZTLDS = STASH && (BASE + ZT <= LIMIT);
-    static constexpr bool ZLDS = STASH && !KSV && (BASE + ZP + (ZTLDS ? ZT : 0) <= LIMIT);
-    static constexpr bool MULDS = KSV ? (STASH && BASE + (ZTLDS ? ZT : 0) + MU <= LIMIT)
-                                      : (ZLDS && (BASE + ZP + (ZTLDS ? ZT : 0) + MU <= LIMIT));
+    static constexpr bool ZLDS = STASH && (BASE + ZP + (ZTLDS ? ZT : 0) <= LIMIT);
+    static constexpr bool MULDS = ZLDS && (BASE + ZP + (ZTLDS ? ZT : 0) + MU <= LIMIT);
     static constexpr int EXTRA = (ZLDS ? ZP : 0) + (ZTLDS ? ZT : 0) + (MULDS ? MU : 0);   // variants without the K^-1 image
 };
 
@@ -169,8 +167,7 @@ constexpr bool rev_extra_wave(int nblk, bool stash) { return stash ? (nblk != 16
 template <int NBLK, int RB, int DK, bool BLDS, bool STASH, int MODE, int KD = 4, bool KSV = false>
 __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, STASH) ? 1 : 0))) void rev_kernel(RevArgs a)
 {
-    static_assert(!(KSV && STASH) || rev_extra_wave(NBLK, STASH), "stash mode reads kept kernel tiles through the stash-writer wave");
-    constexpr bool KSW = KSV && STASH;                  // stash mode, kernel tiles kept: the stash-writer wave brings them in
+    static_assert(!(KSV && STASH), "kernel tiles are kept for the register-resident tile heights only");
     constexpr bool BREG = false;
     typedef Tile<NBLK, RB, DK, BREG> TT;
     constexpr int W = TT::W, NT = TT::NT, MP = TT::MP, KS = TT::KS;
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
 
     extern __shared__ double lds[];
     double* xq0 = lds;                                  // [2][4*DK][17]: this step's and the next step's inputs
-    typedef RevLds<NBLK, RB, DK, STASH, KSV> RL;
+    typedef RevLds<NBLK, RB, DK, STASH> RL;
     constexpr bool PALIAS = RL::PALIAS && !BLDS;        // `part` shares the K tile's LDS (see RevLds)
     constexpr int PSL = (JB > 2 ? JB : 2) * 256;
     double* Kt = xq0 + 2 * 4 * DK * PD;                 // [MP][17]
@@ -569,35 +566,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     }
     if constexpr (SW) {
         if (w == W) {
-            // KSW: this wave also brings the KEPT kernel tile of every step in -- the record's K part is the dense
-            // row-major (16 NBLK x 16) tile, NBLK x 256 doubles: 2 NBLK 16-byte loads per lane, issued behind barrier 5 of the
-            // step before (in flight under phases G / D), written to the padded LDS tile behind barrier 6, when the K tile's
-            // LDS (by then the partial tiles') is free.  The row-block waves then have no phase B at all: 6 MFMAs and four
-            // exponentials per lane and row block, 14-16 % of a stash-mode step.
-            typedef double dd2 __attribute__((ext_vector_type(2)));
-            constexpr int NKV = KSW ? 2 * NBLK : 1;
-            dd2 kv[NKV];
-            const int64_t G16s = (int64_t(a.N) + 15) >> 4;
-            const int TSs = saved_tile_stride(NBLK, a.ksave);
-            auto kload = [&](int t) {
-                if constexpr (KSW) {
-                    const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * a.T + t);
-                    const double* kp = a.a2s + (slot * G16s + (c0 >> 4)) * TSs + NBLK * 256 + 2 * l;
-#pragma unroll
-                    for (int k = 0; k < NKV; ++k) kv[k] = *reinterpret_cast<const dd2*>(kp + 128 * k);
-                }
-            };
-            auto kstore = [&]() {
-                if constexpr (KSW) {
-#pragma unroll
-                    for (int k = 0; k < NKV; ++k) {
-                        const int f = 2 * l + 128 * k, m = f >> 4, n = f & 15;
-                        Kt[m * PD + n] = kv[k][0];
-                        Kt[m * PD + n + 1] = kv[k][1];
-                    }
-                }
-            };
-            if (nsteps > 0) { kload(t_of(0)); kstore(); }
             __syncthreads();                                         // (the barrier in front of the step loop)
             for (int step = 0; step < nsteps; ++step) {
                 const int64_t slot = wg_linear * a.chunk_steps + step;
@@ -624,9 +592,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 }
                 if constexpr (PALIAS) __syncthreads();               // (the row-block waves: partial tiles over the K tile)
                 __syncthreads();                                     // 5
-                if (step + 1 < nsteps) kload(t_of(step + 1));        // (KSW) next step's kernel tile: in flight under G / D
                 __syncthreads();                                     // 6
-                if (step + 1 < nsteps) kstore();                     // (KSW) the K tile's LDS is free again
             }
             return;
         }
@@ -644,10 +610,9 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     // KSV: the saved [A2 | K] rows of this wave for the NEXT step, issued behind barrier 5 of the current one
     const int64_t G16 = (N + 15) >> 4;
     const int TS = saved_tile_stride(NBLK, a.ksave);
-    constexpr bool KREG = KSV && !STASH;                // ... through registers (the register-resident tile heights)
-    d4 a2n[KREG ? RB : 1], kn[KREG ? RB : 1];
+    d4 a2n[KSV ? RB : 1], kn[KSV ? RB : 1];
     auto load_saved = [&](int t) {
-        if constexpr (KREG) {
+        if constexpr (KSV) {
             const int64_t slot = (MODE == MODE_FWD) ? int64_t(t) : (int64_t(run) * T + t);
             const double* ap = a.a2s + (slot * G16 + (c0 >> 4)) * TS + l;
 #pragma unroll
@@ -703,7 +668,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         // vmcnt retires in order, so anything issued before this wait (the next step's inputs below) would be waited for too
         d4 kreg[RB];
         CBF_STAMP_MARK0();
-        if constexpr (KREG) {
+        if constexpr (KSV) {
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 kreg[i] = kn[i];
@@ -718,7 +683,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         CBF_STAMP_MARK(10);
         // A2 rows of this wave, if the forward evaluation kept them (consumed after the second barrier)
         d4 a2[RB];
-        if constexpr (KREG) {
+        if constexpr (KSV) {
 #pragma unroll
             for (int i = 0; i < RB; ++i) a2[i] = a2n[i];
         } else if (a.a2s) {
@@ -776,13 +741,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         }
         CBF_STAMP_MARK(2);
         CBF_STAMP_BARRIER(1);
-        if constexpr (KSW) {
-            // the kept kernel tile of this step is in the LDS tile (the stash-writer wave put it there): this wave's rows
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) kreg[i][r] = Kt[(16 * rbs[i] + 4 * r + g) * PD + nl];
-        }
 
         // ---- C: A2 rows of this wave (only when the forward evaluation did not keep them)
         CBF_STAMP_MARK0();

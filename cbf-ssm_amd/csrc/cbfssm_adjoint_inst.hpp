@@ -58,18 +58,6 @@ int launch_rev_k(const RevArgs& a, dim3 grid, hipStream_t st)
         typedef RevLds<NBLK, C::RB, DK, C::STASH> RL;
         static_assert(RL::BASE_PLAIN == G::LDS_BASE, "LDS layout");
         const size_t lds = size_t(RL::BASE + RL::EXTRA) * sizeof(double);
-        if constexpr (C::STASH && rev_extra_wave(NBLK, C::STASH)) {
-            if (a.ksave && a.a2s) {          // stash mode with kept kernel tiles: the stash-writer wave brings them in
-                typedef RevLds<NBLK, C::RB, DK, C::STASH, true> RLK;
-                const size_t ldsk = size_t(RLK::BASE + RLK::EXTRA) * sizeof(double);
-                auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE, KD, true>;
-                int rc = set_lds(k, ldsk);
-                if (rc) return rc;
-                hipLaunchKernelGGL(k, grid, block, ldsk, st, a);
-                hipError_t e = hipGetLastError();
-                return e == hipSuccess ? 0 : -int(e) - 1000;
-            }
-        }
         if constexpr (!C::STASH) {
             if (a.ksave && a.a2s) {
                 auto k = rev_kernel<NBLK, C::RB, DK, false, C::STASH, MODE, KD, true>;

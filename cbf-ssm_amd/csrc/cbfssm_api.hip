@@ -1109,15 +1109,7 @@ int cbfssm_backward_pass_f64(const cbfssm_problem* p, const cbfssm_pack_layout* 
 // Tile heights whose adjoint holds its accumulators in registers (M <= 112) also keep the kernel tile K = k(Z, x_t) of
 // every step next to its A2 tile: the adjoint then reads it instead of rebuilding it (6 MFMAs and four exponentials per
 // lane and step, a whole phase of its step), for as many bytes again.  CBFSSM_NO_SAVE_K=1 switches it off (A/B runs).
-// Round 4: also at 10 and 13 row blocks (stash mode with a stash-writer wave, which brings the tile into LDS: cbfssm_adjoint.hpp,
-// KSW); not above -- at 20 row blocks the A2 tiles alone are 196 GB at the C5 shape.  CBFSSM_SAVE_K_MAX overrides the height.
-static int save_k(const cbfssm_pack_layout* L)
-{
-    if (getenv("CBFSSM_NO_SAVE_K")) return 0;
-    int hmax = 13;
-    if (const char* e = getenv("CBFSSM_SAVE_K_MAX")) hmax = atoi(e);
-    return (L->NBLK <= 7 || (L->NBLK <= hmax && L->NBLK != 16 && L->NBLK <= 13)) ? 1 : 0;
-}
+static int save_k(const cbfssm_pack_layout* L) { return (L->NBLK <= 7 && !getenv("CBFSSM_NO_SAVE_K")) ? 1 : 0; }
 
 int64_t cbfssm_saved_a2_elems(const cbfssm_problem* p, const cbfssm_pack_layout* L, int backward)
 {
