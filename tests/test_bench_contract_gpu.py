@@ -61,3 +61,23 @@ def test_variant_bench_lines(model):
     roof = rec['roofline']
     assert roof['bound'] == 'mfma' and roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'])
     assert set(roof['kernel_ms']) == {'forward_pass', 'forward_pass_adjoint'}
+
+
+def test_two_rank_bench_line_on_one_device():
+    """The N > 1 path of bench.py end to end, two ranks sharing this one GPU over gloo (CBFSSM_BENCH_ONE_DEVICE=1; the real run
+    is one rank per GPU over RCCL): the default workload is the N = 1 one, and the line carries its own single-rank baseline, the
+    efficiency that follows from it and the 8-GPU config (C4) with its own baseline."""
+    env = dict(os.environ, CBFSSM_BENCH_ONE_DEVICE='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', '29541', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3',
+                          '--warmup', '1'], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['workload'].startswith('C3-Sarcos') and rec['config']['global_batch'] == 512
+    assert rec['single_rank']['steps_per_s'] > 0
+    assert rec['scaling_efficiency'] == pytest.approx(rec['value'] / (2 * rec['single_rank']['steps_per_s']), rel=1e-9)
+    c4 = rec['eight_gpu_config']
+    assert c4['workload'].startswith('C4-Sarcos-M200') and c4['single_rank']['steps_per_s'] > 0
+    assert rec['collective']['ranks'] == 2 and rec['collective']['sum_checked'] is True
