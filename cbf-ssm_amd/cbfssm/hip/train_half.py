@@ -69,10 +69,16 @@ def gru_recognition(recog, u, y, recog_len):
 class HipHalfGrad:
     """loss and gradients of CBFSSMHALF for one mini-batch on one device."""
 
-    def __init__(self, config, device, dist=None, variant='half'):
+    def __init__(self, config, device, dist=None, variant='half', dtype='float64'):
         """variant 'half': CBFSSMHALF.  variant 'prssm': the PR-SSM baseline (reference cbfssm/model/prssm.py) -- the same
         pass with the Kalman update switched off everywhere (free run), loss = -(lambda0 * loglik - KL_z) with the KL
-        prior factorised WITHOUT jitter (prssm.py:81-82,96) and one shared lengthscale (prssm.py:40)."""
+        prior factorised WITHOUT jitter (prssm.py:81-82,96) and one shared lengthscale (prssm.py:40).
+
+        dtype 'float32' (the reference's model dtype argument, cbfssmhalf.py:17 / prssm.py:17): the time loop and its adjoint
+        compute in float32 (cbfssm_half_forward_pass_f32 / _bwd_f32); K_mm / Cholesky / K^-1, the recognition model, the train
+        tail and the optimizer step stay float64, as in HipElboGrad."""
+        assert dtype in ('float64', 'float32')
+        self.f32 = dtype == 'float32'
         self.config = config
         self.variant = variant
         self.device = torch.device(device)
@@ -88,7 +94,11 @@ class HipHalfGrad:
         lf0 = float(config['loss_factors'][0])
         self.cL = lf0 if variant == 'prssm' else lf0 / self.S
         self.pack_kl = GPPack(self.M, self.D, self.dim_x, self.device) if variant == 'prssm' else None
-        self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device)
+        self.pack_f = GPPack(self.M, self.D, self.dim_x, self.device, ops.gp_form_mode_f32(config) if self.f32 else None)
+        if self.f32:
+            self.pack_f.cond_threshold = min(self.pack_f.cond_threshold, ops.F32_FORM_COND)
+            # per-workgroup slabs of the float32 adjoint: the non-stash layout at every tile height (matrix section included)
+            self.slab32_f = int(_l.load().cbfssm_rev32_slab_elems(C.byref(self.pack_f.layout)))
         self.stash = bool(self.pack_f.layout.rev_stash)
         self.stash_bytes = int(float(config.get('adjoint_stash_gib', 4.0)) * 2 ** 30)
         self._stash_buf = None
@@ -177,10 +187,17 @@ class HipHalfGrad:
         if self.pack_kl is not None:
             self.pack_kl.prepare(p[pre + 'zeta_pos'], c['ls'], c['var'], p[pre + 'zeta_mean'], c['zvar'], jitter=0.0)
         lay = C.byref(self.pack_f.layout)
-        rc = self._timed('forward_pass', lambda: lib.cbfssm_half_forward_pass_f64(
-            pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(x0),
-            _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st))
-        _l.check(rc, 'cbfssm_half_forward_pass_f64')
+        if self.f32:
+            b32 = C.c_void_p(self.pack_f.pack_f32().data_ptr())
+            rc = self._timed('forward_pass', lambda: lib.cbfssm_half_forward_pass_f32(
+                pb, lay, b32, _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(x0),
+                _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st))
+            _l.check(rc, 'cbfssm_half_forward_pass_f32')
+        else:
+            rc = self._timed('forward_pass', lambda: lib.cbfssm_half_forward_pass_f64(
+                pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y), _ptr(x0),
+                _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), _ptr(ws.kl_part), st))
+            _l.check(rc, 'cbfssm_half_forward_pass_f64')
         rc = lib.cbfssm_loglik_moments_f64(pb, _ptr(c['var_y']), _ptr(y), _ptr(ws.x), _ptr(ws.ll_part),
                                            _ptr(ws.pred_mean), _ptr(ws.pred_var), _ptr(ws.int_mean), _ptr(ws.int_var), st)
         _l.check(rc, 'cbfssm_loglik_moments_f64')
@@ -213,7 +230,12 @@ class HipHalfGrad:
             ws.n_f = int(lib.cbfssm_rev_workgroups(C.byref(prob), 0))
             ws.x = torch.zeros(prob.T, N, prob.dim_x, **f)
             ws.fmv_f = torch.zeros(max(prob.T - 1, 0), N, prob.dim_x, 2, **f)
-            n_a2 = int(lib.cbfssm_saved_a2_elems(C.byref(prob), C.byref(self.pack_f.layout), 0))
+            if self.f32:    # every step's [A2 | kernel tile] registers of the float32 pass, float32 (held in a float64 buffer)
+                n_a2 = int(lib.cbfssm_saved_a2_f32_elems(C.byref(prob), C.byref(self.pack_f.layout), 0))
+                assert n_a2 > 0 or prob.T == 1
+                n_a2 = max((n_a2 + 1) // 2, 1)
+            else:
+                n_a2 = int(lib.cbfssm_saved_a2_elems(C.byref(prob), C.byref(self.pack_f.layout), 0))
             if getattr(self, 'tile_pool', None) is None:
                 self.tile_pool = ops.TilePool(self.device)
             ws.a2s_f, _ = self.tile_pool.get(n_a2, 0)
@@ -227,7 +249,7 @@ class HipHalfGrad:
             ws.y2 = torch.zeros(prob.T, N, max(0, prob.dim_x - prob.dim_y), **f)      # (surface compatibility)
             ws.gx0 = torch.zeros(N, prob.dim_x, **f)
             ws.gx_carry = torch.zeros(N, prob.dim_x, **f)
-            ws.gpart_f = torch.zeros((ws.n_f + 32) * self.slab_f, **f)
+            ws.gpart_f = torch.zeros((ws.n_f + 32) * (self.slab32_f if self.f32 else self.slab_f), **f)
             ws.red = torch.zeros(self.slab_f + 3 + prob.dim_y, **f)     # [slab | loglik, kl_x, 0, d loss / d var_y]
             self._ws[key] = ws
         return self._ws[key]
@@ -297,7 +319,32 @@ class HipHalfGrad:
         N = B * self.S
         groups = (N + 15) // 16
         gB = None
-        if not self.stash:
+        g_mode = 0
+        if self.f32:
+            # one launch at every tile height; the matrix section of its slab holds G = K^-1 (d loss / d K^-1) K^-1 (full up to
+            # 10 row blocks, the lower block triangle of the symmetrised sum from 13: include/cbfssm_hip.h)
+            g_mode = 2 if self.pack_f.layout.NBLK >= 13 else 1
+            s32 = self.slab32_f
+            rc = self._timed('forward_pass_adjoint', lambda: lib.cbfssm_half_forward_pass_bwd_f32(
+                pb, lay, C.c_void_p(self.pack_f.buf32.data_ptr()), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y),
+                _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0),
+                _ptr(ws.gpart_f), st))
+            _l.check(rc, 'cbfssm_half_forward_pass_bwd_f32')
+            if not self.stash:
+                assert s32 == sf
+                _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), sf, ws.n_f, _ptr(red[:sf]), st), 'reduce f')
+            else:
+                # (the float64 slab of these tile heights has no matrix section: hand it to the tail as the image it expects)
+                nb = self.pack_f.layout.NBLK
+                nimg, og = nb * nb * 256, 2 * nb * 256
+                if getattr(self, '_tmp32', None) is None:
+                    self._tmp32 = torch.zeros(s32 + nimg, dtype=torch.float64, device=dev)
+                t32, gB = self._tmp32[:s32], self._tmp32[s32:]
+                _l.check(lib.cbfssm_reduce_partials_f64(_ptr(ws.gpart_f), s32, ws.n_f, _ptr(t32), st), 'reduce f')
+                red[:og].copy_(t32[:og])
+                red[og:sf].copy_(t32[og + nimg:])
+                gB.copy_(t32[og:og + nimg])
+        elif not self.stash:
             rc = self._timed('forward_pass_adjoint', lambda: lib.cbfssm_half_forward_pass_bwd_f64(
                 pb, lay, _ptr(self.pack_f.buf), _ptr(c['var_x']), _ptr(c['var_y']), _ptr(u), _ptr(y),
                 _ptr(eps_f) if eps_f.numel() else None, _ptr(ws.x), _ptr(ws.fmv_f), _ptr(ws.a2s_f), cL, _ptr(ws.gx0),
@@ -383,7 +430,7 @@ class HipHalfGrad:
                 self.tail_work = torch.zeros(nw, dtype=torch.float64, device=dev)
             gall = torch.zeros(ngp + sum(rgrads[k].numel() for k in rnames), dtype=torch.float64, device=dev)
             rc = lib.cbfssm_train_tail_half_f64(lay, _ptr(self.pack_f.buf), _ptr(self.pack_kl.buf) if self.pack_kl is not None else None,
-                                                int(lsc.numel() == 1), _ptr(red), _ptr(gB), 0, self.dim_y, _ptr(pflat), _ptr(cflat),
+                                                int(lsc.numel() == 1), _ptr(red), _ptr(gB), 0, g_mode, self.dim_y, _ptr(pflat), _ptr(cflat),
                                                 _ptr(self.tail_work), _ptr(gall), st)
             _l.check(rc, 'cbfssm_train_tail_half_f64')
             grads = FlatDict()
@@ -399,6 +446,19 @@ class HipHalfGrad:
             return loss, grads, terms
 
         grads = dict(rgrads)
+        if self.f32:
+            # (cross-check path) the matrix section holds G = K^-1 (d loss / d K^-1) K^-1; this restatement expects K G K
+            from .train import _unpack_c
+            nb, M = self.pack_f.layout.NBLK, self.M
+            G = _unpack_c(gB if gB is not None else red[2 * nb * 256:2 * nb * 256 + nb * nb * 256], nb, nb)
+            if g_mode == 2:
+                blk = torch.arange(16 * nb, device=dev) // 16
+                G = torch.where(blk[:, None] >= blk[None, :], G, torch.zeros_like(G))
+            G = 0.5 * (G + G.T)[:M, :M]
+            K = self.pack_f.Kmm + self.pack_f.scal[_l.SCAL_JITTER] * torch.eye(M, dtype=torch.float64, device=dev)
+            Bd = torch.zeros(16 * nb, 16 * nb, dtype=torch.float64, device=dev)
+            Bd[:M, :M] = K @ G @ K
+            gB = Bd.view(nb, 4, 4, nb, 16).permute(0, 3, 1, 2, 4).reshape(-1)
         gz, gmu, gs2, gvar, gls, small = self._gp_adjoint(self.pack_f, red[:sf], p[pre + 'zeta_pos'], c['ls'], c['var'],
                                                           p[pre + 'zeta_mean'], c['zvar'], self.dim_x, gB, self.pack_kl)
         grads[pre + 'zeta_pos'] = gz

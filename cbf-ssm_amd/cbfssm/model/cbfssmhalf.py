@@ -45,8 +45,6 @@ class CBFSSMHALF(CBFSSM):
 
     def _make_engine(self, sess, dist):
         from ..hip.train_half import HipHalfGrad, half_param_names
-        if self.dtype != 'float64':
-            raise NotImplementedError('CBFSSMHALF computes in float64 (float32 arithmetic is built for CBFSSM)')
-        return HipHalfGrad(self.config, sess.device, dist), half_param_names(self.config)
+        return HipHalfGrad(self.config, sess.device, dist, dtype=self.dtype), half_param_names(self.config)
 
     _noise_with_backward = False

@@ -49,9 +49,7 @@ class PRSSM(CBFSSM):
 
     def _make_engine(self, sess, dist):
         from ..hip.train_half import HipHalfGrad, half_param_names
-        if self.dtype != 'float64':
-            raise NotImplementedError('PRSSM computes in float64 (float32 arithmetic is built for CBFSSM)')
-        return HipHalfGrad(self.config, sess.device, dist, variant='prssm'), half_param_names(self.config, 'prssm')
+        return HipHalfGrad(self.config, sess.device, dist, variant='prssm', dtype=self.dtype), half_param_names(self.config, 'prssm')
 
     def _execute(self, sess, names, feed, lazy=False):
         feed = dict(feed)

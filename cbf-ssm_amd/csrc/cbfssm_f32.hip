@@ -84,6 +84,8 @@ struct Args32 {
                           // recomputing both (cbfssm_rev32.hip, KSV)
     double* h_all;        // optional (backward runs): every step's output of both runs
     int tri;              // 1: two-triangular GP form (layout->gp_form == CBFSSM_GP_FORM_TRI)
+    int half;             // forward-only variants (CBFSSMHALF / PRSSM, cbfssmhalf.py:117-172): x_0 from x0, the Kalman update on
+    const double* x0;     // the observed dims only (d < dim_y), var_y with dim_y entries; x0: (B, dim_x) recognition-model output
     int group0;           // chain-group split: this launch covers the 16-chain groups [group0, group0 + gridDim.x)
     int nseg0;
     // predict
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
         act[qi] = (q < 4) && (d < Do);
         const int dc = act[qi] ? d : 0;
         vx[qi] = float(a.var_x[dc]);
-        vy[qi] = (MODE == MODE_FWD) ? float(a.var_y[dc]) : 0.0f;
+        vy[qi] = (MODE == MODE_FWD) ? float(a.var_y[(a.half && dc >= a.dim_y) ? 0 : dc]) : 0.0f;   // half: var_y has dim_y entries
         il[qi] = a.pk.invl[dc];
         lin[qi] = 0.0;
         lp[qi].init();
@@ -428,8 +430,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
         if (act[qi]) {
             float v;
             if (MODE == MODE_FWD) {
-                const double v64 = (d < a.dim_y) ? a.y[(int64_t(bq) * T) * a.dim_y + d]
-                                                 : a.y2_in[int64_t(c) * (a.dim_x - a.dim_y) + (d - a.dim_y)];
+                // x_0 = y_tilde[:, 0] = [y_0, y2_0]  (cbfssm.py:97,168); half: the recognition model's output (cbfssmhalf.py:106)
+                const double v64 = a.half ? a.x0[int64_t(bq) * a.dim_x + d]
+                                          : ((d < a.dim_y) ? a.y[(int64_t(bq) * T) * a.dim_y + d]
+                                                           : a.y2_in[int64_t(c) * (a.dim_x - a.dim_y) + (d - a.dim_y)]);
                 if (cval) a.x_out[int64_t(c) * a.dim_x + d] = v64;                      // x_0 = y_tilde[:, 0]  (cbfssm.py:168)
                 v = float(v64);
             } else {
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
                 ytil[qi] = 0.0f;
                 if (act[qi]) {
                     if (d < a.dim_y) ytil[qi] = float(a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d]);
-                    else ytil[qi] = float(a.y2_in[(int64_t(t + 1) * N + c) * (a.dim_x - a.dim_y) + (d - a.dim_y)]);
+                    else if (!a.half) ytil[qi] = float(a.y2_in[(int64_t(t + 1) * N + c) * (a.dim_x - a.dim_y) + (d - a.dim_y)]);
                 }
             }
         } else {
@@ -509,7 +513,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass32_kernel(Arg
                         const float ydiff = ytil[qi] - fmean;
                         const float mu = fmean + kk * ydiff;
                         const float sig = kk * vyt;                 // = (1-k)^2 fvar + k^2 v with 1 - k = v / s   (:219-220)
-                        const bool do_cond = a.condition || (t < R - 1);                   // :227
+                        // (half: the hidden dims get no Kalman update -- mu = fmean, sig = fvar, no KL term)
+                        const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // :227
                         outv = do_cond ? (mu + eps_t * (sig * rsqrt32(sig))) : (fmean + eps_t * (fvar * rsqrt32(fvar)));
                         if (do_cond && cval) {
                             lin[qi] += double(kk * (ydiff * ydiff * rs - 1.0f));           // (sig + (mu-fmean)^2)/fvar - 1  (:232)
@@ -621,7 +626,6 @@ static int fill32(Args32& a, const cbfssm_problem* p, const cbfssm_pack_layout* 
 {
     if (!p || !L || !pack32) return fail(-1, "null pointer");
     if (p->B < 1 || p->S < 1 || p->T < 1 || p->recog_len < 1) return fail(-1, "B, S, T, recog_len must be >= 1");
-    if (p->half) return fail(-1, "the float32 passes serve CBFSSM only");
     if (p->ngroups > 0 && (p->group0 < 0 || p->group0 + p->ngroups > (p->B * p->S + 15) / 16)) return fail(-1, "bad chain-group range");
     if (L->D != p->dim_x + p->dim_u || L->Do != Do || L->M != p->M) return fail(-1, "pack does not match the problem");
     memset(&a, 0, sizeof(a));
@@ -694,6 +698,7 @@ int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* 
                              const double* eps_b, double* y2, double* h_all, double* fmv_b, float* a2s_b, double* ent_part,
                              void* stream)
 {
+    if (p && p->half) return fail(-1, "the forward-only variants have no backward runs");
     Args32 a;
     int rc = fill32(a, p, L, pack32_b, p ? p->dim_x - p->dim_y : 0);
     if (rc) return rc;
@@ -708,21 +713,38 @@ int cbfssm_backward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* 
     return rc ? fail(rc, "backward_pass_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;
 }
 
+static int forward32_impl(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f, const double* var_x,
+                          const double* var_y, const double* u, const double* y, const double* y2, const double* x0,
+                          const double* eps_f, double* x, double* fmv_f, float* a2s_f, double* kl_part, void* stream)
+{
+    Args32 a;
+    int rc = fill32(a, p, L, pack32_f, p ? p->dim_x : 0);
+    if (rc) return rc;
+    if (!var_x || !var_y || !u || !y || !x || !kl_part || (p->T > 1 && !eps_f)) return fail(-1, "null pointer");
+    if (p->half ? !x0 : (p->dim_x > p->dim_y && !y2)) return fail(-1, p->half ? "x0 is null" : "y2 is null");
+    a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x; a.part_out = kl_part;
+    a.fmv = fmv_f; a.a2s = a2s_f; a.half = p->half; a.x0 = x0;
+    dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 1);
+    rc = dispatch32(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
+    return rc ? fail(rc, "forward_pass_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;
+}
+
+int cbfssm_half_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
+                                 const double* var_x, const double* var_y, const double* u, const double* y,
+                                 const double* x0, const double* eps_f, double* x, double* fmv_f, float* a2s_f,
+                                 double* kl_part, void* stream)
+{
+    if (!p || !p->half) return fail(-1, "problem->half must be 1");
+    return forward32_impl(p, L, pack32_f, var_x, var_y, u, y, nullptr, x0, eps_f, x, fmv_f, a2s_f, kl_part, stream);
+}
+
 int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
                             const double* var_x, const double* var_y, const double* u, const double* y,
                             const double* y2, const double* eps_f, double* x, double* fmv_f, float* a2s_f, double* kl_part,
                             void* stream)
 {
-    Args32 a;
-    int rc = fill32(a, p, L, pack32_f, p ? p->dim_x : 0);
-    if (rc) return rc;
-    if (!var_x || !var_y || !u || !y || !x || !kl_part || (p->dim_x > p->dim_y && !y2) || (p->T > 1 && !eps_f))
-        return fail(-1, "null pointer");
-    a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.y2_in = y2; a.x_out = x; a.part_out = kl_part;
-    a.fmv = fmv_f; a.a2s = a2s_f;
-    dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 1);
-    rc = dispatch32(L->NBLK, L->DK, MODE_FWD, a, grid, (hipStream_t)stream);
-    return rc ? fail(rc, "forward_pass_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc) : 0;
+    if (p && p->half) return fail(-1, "problem->half is set: use cbfssm_half_forward_pass_f32");
+    return forward32_impl(p, L, pack32_f, var_x, var_y, u, y, y2, nullptr, eps_f, x, fmv_f, a2s_f, kl_part, stream);
 }
 
 }  // extern "C"

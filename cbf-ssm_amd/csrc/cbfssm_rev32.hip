@@ -53,6 +53,8 @@ struct Rev32Args {
     int cb0;               // first Kinvbar column block this launch accumulates
     int first;             // 1: this launch also produces every other adjoint (and the y2 adjoint); 0: Kinvbar columns only
     int tri;               // 1: the products with K^-1 run as two triangular products (layout->gp_form == CBFSSM_GP_FORM_TRI)
+    int half;              // forward-only variants (CBFSSMHALF / PRSSM): the forward pass of problem->half = 1
+    double* gx0;           // half: (N, dim_x) d loss / d x_0 per chain (summed over the particles by the caller)
     int group0, gtotal;    // chain-group split: this launch covers groups [group0, group0 + gridDim.x) of gtotal
 };
 
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         act[qi] = (q < 4) && (d < Do);
         const int dc = act[qi] ? d : 0;
         vx[qi] = float(a.var_x[dc]);
-        vy[qi] = (MODE == MODE_FWD) ? float(a.var_y[dc]) : 0.0f;
+        vy[qi] = (MODE == MODE_FWD) ? float(a.var_y[(a.half && dc >= a.dim_y) ? 0 : dc]) : 0.0f;
         il[qi] = a.pk.invl[dc];
         ivy[qi] = (MODE == MODE_FWD) ? 1.0f / vy[qi] : 0.0f;
         gcar[qi] = 0.0f; gdir[qi] = 0.0f; gvx[qi] = 0.0; gvy[qi] = 0.0;
@@ -328,8 +330,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                 const double* o = a.fmv + ((slot * N + c) * Do + d) * 2;
                 fm[qi] = float(o[0]); fv[qi] = float(o[1]);
                 if (MODE == MODE_FWD) {
-                    yin[qi] = (d < a.dim_y) ? float(a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d])
-                                            : float(a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)]);
+                    if (d < a.dim_y) yin[qi] = float(a.y[(int64_t(bq) * T + (t + 1)) * a.dim_y + d]);
+                    else if (!a.half) yin[qi] = float(a.y2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)]);
                 } else {
                     const bool write = (run == 0) ? (tm < R) : (tm >= R);
                     if (write) yin[qi] = float(a.gy2[(int64_t(t) * N + c) * Do + d]);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                     const float fmean = fmi[qi], fvar = fvi[qi];
                     const float gout = gcar[qi];
                     if (MODE == MODE_FWD) {
-                        const bool do_cond = (a.condition || (t < R - 1));                          // cbfssm.py:227
+                        const bool do_cond = (a.condition || (t < R - 1)) && !(a.half && d >= a.dim_y);   // cbfssm.py:227
                         if (do_cond) {
                             const float ytil = yin[qi];
                             const float kf1 = a.k_factor - 1.0f;
@@ -381,11 +383,11 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                             gfv += gs;
                             if (first) gvy[qi] += double(gvyt);
                             gfv += kf1 * gvyt;                                  // vyt = vy + (kf - 1) fvar
-                            if (first && d >= a.dim_y) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = double(gyt);
+                            if (first && d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = double(gyt);
                         } else {
                             gfm = gout;                                         // x' = fmean + eps sqrt(fvar), no KL term
                             gfv = gout * eps_t * 0.5f * rsqrt32(fvar);
-                            if (first && d >= a.dim_y) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
+                            if (first && d >= a.dim_y && !a.half) a.gy2[(int64_t(t + 1) * N + c) * dob + (d - a.dim_y)] = 0.0;
                         }
                     } else {
                         // out = fmean + eps sqrt(fvar); entropy term on written steps          (cbfssm.py:150-156)
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
         for (int qi = 0; qi < QPW; ++qi) {
             const int d = 4 * g + (w + qi * W);
             ycur[qi] = 0.0f;
-            if (MODE == MODE_FWD && act[qi] && d < a.dim_y && t >= 1) ycur[qi] = float(a.y[(int64_t(bq) * T + t) * a.dim_y + d]);
+            if (MODE == MODE_FWD && act[qi] && d < a.dim_y && (t >= 1 || a.half))
+                ycur[qi] = float(a.y[(int64_t(bq) * T + t) * a.dim_y + d]);
         }
         f4 ebar[RB];
         {
@@ -757,10 +760,13 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
                             if (MODE == MODE_FWD) {
                                 const int d = 4 * g + q;
                                 if (act[qi] && cvalid) {
-                                    if (t >= 1 && d < a.dim_y) {
+                                    if ((t >= 1 || a.half) && d < a.dim_y) {
                                         gin += -a.cL * (ycur[qi] - hcur[qi]) * ivy[qi];  // log-likelihood term of x_t
                                     }
-                                    if (first && t == 0 && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = double(gin);
+                                    if (first && t == 0) {
+                                        if (a.half) a.gx0[int64_t(c) * a.dim_x + d] = double(gin);        // x_0 = recognition model
+                                        else if (d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = double(gin);   // x_0 = y_tilde_0
+                                    }
                                 }
                                 gcar[qi] = gin;
                             } else {
@@ -786,7 +792,15 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void rev32_kernel(Rev3
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             const int d = 4 * g + (w + qi * W);
-            if (act[qi] && cvalid && d >= a.dim_y) a.gy2[int64_t(c) * dob + (d - a.dim_y)] = 0.0;
+            if (act[qi] && cvalid) {
+                if (a.half) {
+                    float gv = 0.0f;
+                    if (d < a.dim_y) gv = -a.cL * (float(a.y[(int64_t(bq) * T) * a.dim_y + d]) - float(a.x[int64_t(c) * a.dim_x + d])) / vy[qi];
+                    a.gx0[int64_t(c) * a.dim_x + d] = double(gv);
+                } else if (d >= a.dim_y) {
+                    a.gy2[int64_t(c) * dob + (d - a.dim_y)] = 0.0;
+                }
+            }
         }
     }
 
@@ -920,7 +934,6 @@ static int fill_rev32(Rev32Args& a, const cbfssm_problem* p, const cbfssm_pack_l
 {
     if (!p || !L || !pack32) return fail(-1, "null pointer");
     if (p->B < 1 || p->S < 1 || p->T < 1 || p->recog_len < 1) return fail(-1, "B, S, T, recog_len must be >= 1");
-    if (p->half) return fail(-1, "the float32 passes serve CBFSSM only");
     if (p->ngroups > 0 && (p->group0 < 0 || p->group0 + p->ngroups > (p->B * p->S + 15) / 16)) return fail(-1, "bad chain-group range");
     if (L->D != p->dim_x + p->dim_u || L->Do != Do || L->M != p->M) return fail(-1, "pack does not match the problem");
     memset(&a, 0, sizeof(a));
@@ -950,19 +963,18 @@ int64_t cbfssm_rev32_slab_elems(const cbfssm_pack_layout* L)
     return slab32(L);
 }
 
-int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
-                                const double* var_x, const double* var_y, const double* u, const double* y,
-                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, const float* a2s_f,
-                                double cL, double* gy2, double* gpart, void* stream)
+static int forward_bwd32_impl(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f, const double* var_x,
+                              const double* var_y, const double* u, const double* y, const double* y2, const double* eps_f,
+                              const double* x, const double* fmv_f, const float* a2s_f, double cL, double* gy2, double* gx0,
+                              double* gpart, void* stream)
 {
     Rev32Args a;
     int rc = fill_rev32(a, p, L, pack32_f, p ? p->dim_x : 0);
     if (rc) return rc;
-    if (!var_x || !var_y || !u || !y || !x || !gpart || (p->T > 1 && (!fmv_f || !eps_f)) ||
-        (p->dim_x > p->dim_y && (!y2 || !gy2)))
-        return fail(-1, "null pointer");
+    if (!var_x || !var_y || !u || !y || !x || !gpart || (p->T > 1 && (!fmv_f || !eps_f))) return fail(-1, "null pointer");
+    if (p->half ? !gx0 : (p->dim_x > p->dim_y && (!y2 || !gy2))) return fail(-1, "y2/gy2/gx0 is null");
     a.cL = float(cL); a.var_x = var_x; a.var_y = var_y; a.u = u; a.y = y; a.eps = eps_f; a.x = x; a.y2 = y2; a.gy2 = gy2;
-    a.gpart = gpart; a.fmv = fmv_f; a.a2s = a2s_f;
+    a.gpart = gpart; a.fmv = fmv_f; a.a2s = a2s_f; a.half = p->half; a.gx0 = gx0;
     const int ncb = rev32_ncb(L->NBLK);
     dim3 grid(unsigned(p->ngroups > 0 ? p->ngroups : (a.N + 15) / 16), 1, 1);
     for (int cb0 = 0; cb0 < L->NBLK; cb0 += ncb) {
@@ -971,6 +983,24 @@ int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layou
         if (rc) return fail(rc, "forward_pass_bwd_f32 launch failed (NBLK=%d DK=%d rc=%d)", L->NBLK, L->DK, rc);
     }
     return 0;
+}
+
+int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
+                                const double* var_x, const double* var_y, const double* u, const double* y,
+                                const double* y2, const double* eps_f, const double* x, const double* fmv_f, const float* a2s_f,
+                                double cL, double* gy2, double* gpart, void* stream)
+{
+    if (p && p->half) return fail(-1, "problem->half is set: use cbfssm_half_forward_pass_bwd_f32");
+    return forward_bwd32_impl(p, L, pack32_f, var_x, var_y, u, y, y2, eps_f, x, fmv_f, a2s_f, cL, gy2, nullptr, gpart, stream);
+}
+
+int cbfssm_half_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_f,
+                                     const double* var_x, const double* var_y, const double* u, const double* y,
+                                     const double* eps_f, const double* x, const double* fmv_f, const float* a2s_f, double cL,
+                                     double* gx0, double* gpart, void* stream)
+{
+    if (!p || !p->half) return fail(-1, "problem->half must be 1");
+    return forward_bwd32_impl(p, L, pack32_f, var_x, var_y, u, y, nullptr, eps_f, x, fmv_f, a2s_f, cL, nullptr, gx0, gpart, stream);
 }
 
 int cbfssm_backward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* L, const float* pack32_b,

@@ -190,9 +190,19 @@ __global__ __launch_bounds__(256) void tail_gemm(TailArgs a)
         else if (p.Kkl) {
             // K_mm adjoint with the jitter-free prior (prssm.py:81-82,96): -K^-1 B K^-1 - Kkl B_KL Kkl + 0.5 Do Kkl, and
             // tr(Kbar K_mm) = -tr(K^-1 B) + jitter tr(K^-1 B K^-1) - tr(Kkl B_KL) + 0.5 Do M   (Kkl K_mm = I)
+            const double jit = p.scal[CBFSSM_SCAL_JITTER];
+            double tdiag = (i == j) ? p.T[int64_t(i) * M + i] : 0.0;
+            if (p.gmode) {                                // (float32 adjoint: the data part arrives as G = K^-1 B K^-1, see below)
+                const double gs = gsym_elem(p, i, j);
+                if (i == j) {
+                    double d = 0.0;
+                    for (int k = 0; k < M; ++k) d = fma(gsym_elem(p, i, k), p.Kmm[int64_t(k) * M + i], d);
+                    tdiag += d + jit * gs;
+                }
+                acc += gs;
+            }
             p.G2[int64_t(i) * M + j] = (-acc - acc2 + 0.5 * p.Do * p.Kkl[int64_t(i) * M + j]) * p.Kmm[int64_t(i) * M + j];
-            if (i == j)
-                p.dv[i] = -p.T[int64_t(i) * M + i] + p.scal[CBFSSM_SCAL_JITTER] * acc - p.T2[int64_t(i) * M + i] + 0.5 * p.Do;
+            if (i == j) p.dv[i] = -tdiag + jit * acc - p.T2[int64_t(i) * M + i] + 0.5 * p.Do;
         } else {
             const double kinv = p.Kinv[int64_t(i) * M + j];
             double tdiag = (i == j) ? p.T[int64_t(i) * M + i] : 0.0;
@@ -485,9 +495,10 @@ int64_t cbfssm_train_tail_half_work_elems(const cbfssm_pack_layout* L)
 }
 
 int cbfssm_train_tail_half_f64(const cbfssm_pack_layout* L, const double* pack, const double* pack_kl, int shared_ls,
-                               const double* red, const double* gB_dense, int64_t gB_ld, int dim_y, const double* pflat,
+                               const double* red, const double* gB_dense, int64_t gB_ld, int g_mode, int dim_y, const double* pflat,
                                const double* cflat, double* work, double* gflat, void* stream)
 {
+    if (g_mode < 0 || g_mode > 2) return fail(-1, "g_mode must be 0, 1 or 2");
     if (!L || !pack || !red || !pflat || !cflat || !work || !gflat) return fail(-1, "null pointer");
     if (L->rev_slab <= 0) return fail(-3, "no adjoint slab for M=%d", L->M);
     if (L->M > 320 || L->D > 32) return fail(-3, "tail kernel limits: M <= 320, D <= 32");
@@ -515,7 +526,7 @@ int cbfssm_train_tail_half_f64(const cbfssm_pack_layout* L, const double* pack, 
     p.zmean = cflat + o1; p.zvar = cflat + o2; p.var = cflat + o3; p.ls = cflat + o4;
     p.zvar_unc = pflat + o2; p.var_unc = pflat + o3; p.ls_unc = pflat + o4;
     p.g_z = gflat; p.g_mu = gflat + o1; p.g_s2 = gflat + o2; p.g_var = gflat + o3; p.g_ls = gflat + o4;
-    p.M = M; p.D = D; p.Do = Do; p.NBLK = L->NBLK; p.JB = L->JB; p.stash = L->rev_stash; p.gmode = 0;
+    p.M = M; p.D = D; p.Do = Do; p.NBLK = L->NBLK; p.JB = L->JB; p.stash = L->rev_stash; p.gmode = g_mode;
     a.tail = red + L->rev_slab;
     a.vx_unc = pflat + o5; a.vy_unc = pflat + o6;
     a.g_vx = gflat + o5; a.g_vy = gflat + o6;

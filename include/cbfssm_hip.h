@@ -359,6 +359,17 @@ int cbfssm_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* l
  * adjoint, which then reads them back instead of recomputing the kernel tile and the K^-1 K product (2 F instead of 3 F per GP
  * evaluation; C3: 3.4 GB for both GPs).  Opaque to the host. */
 int64_t cbfssm_saved_a2_f32_elems(const cbfssm_problem* p, const cbfssm_pack_layout* layout, int backward_runs);
+/* The forward pass of the forward-only variants (problem->half = 1: x_0 from the recognition model, Kalman update on the observed
+ * dims only; cbfssmhalf.py:117-172, prssm.py:96-118) in float32 arithmetic, and its adjoint (-> gx0 (N, dim_x): d loss / d x_0
+ * per chain): the float32 counterparts of cbfssm_half_forward_pass_f64 / _bwd_f64. */
+int cbfssm_half_forward_pass_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
+                                 const double* var_x, const double* var_y, const double* u, const double* y,
+                                 const double* x0, const double* eps_f, double* x, double* fmv_f, float* a2s_f,
+                                 double* kl_part, void* stream);
+int cbfssm_half_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
+                                     const double* var_x, const double* var_y, const double* u, const double* y,
+                                     const double* eps_f, const double* x, const double* fmv_f, const float* a2s_f, double cL,
+                                     double* gx0, double* gpart, void* stream);
 int64_t cbfssm_rev32_slab_elems(const cbfssm_pack_layout* layout);
 int cbfssm_forward_pass_bwd_f32(const cbfssm_problem* p, const cbfssm_pack_layout* layout_f, const float* pack32_f,
                                 const double* var_x, const double* var_y, const double* u, const double* y,
@@ -419,12 +430,14 @@ int cbfssm_train_tail_g_f64(const cbfssm_param_layout* pl, const cbfssm_pack_lay
  * 1 with shared_ls: PR-SSM's one lengthscale for all input dimensions, prssm.py:40] | var_x [Do] | var_y [dim_y].
  * red = [slab | loglik, kl_x, entropy (0), dloss/dvar_y[dim_y]] (cbfssm_reduce_partials_f64 + cbfssm_data_tail_f64).
  * pack_kl: NULL, or (PR-SSM) the pack of the same parameters prepared with jitter 0 -- the prior-KL terms then use the
- * jitter-free K_mm^-1 as the reference factorises the prior without jitter.  work: cbfssm_train_tail_half_work_elems doubles.
+ * jitter-free K_mm^-1 as the reference factorises the prior without jitter.  g_mode: the form of the matrix section, as in
+ * cbfssm_train_tail_g_f64 (0 after the float64 adjoint, 1 / 2 after cbfssm_half_forward_pass_bwd_f32).
+ * work: cbfssm_train_tail_half_work_elems doubles.
  */
 int64_t cbfssm_train_tail_half_work_elems(const cbfssm_pack_layout* layout);
 int cbfssm_train_tail_half_f64(const cbfssm_pack_layout* layout, const double* pack, const double* pack_kl, int shared_ls,
-                               const double* red, const double* gB_dense, int64_t gB_ld, int dim_y, const double* pflat,
-                               const double* cflat, double* work, double* gflat, void* stream);
+                               const double* red, const double* gB_dense, int64_t gB_ld, int g_mode, int dim_y,
+                               const double* pflat, const double* cflat, double* work, double* gflat, void* stream);
 
 /*
  * Recognition model of the forward-only variants: x_0 = dense(GRUCell(16)(the first recog_len steps of [u, y], reversed))
