@@ -1335,7 +1335,10 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB)) void pass_kernel(PassA
             if (gx * NC + cq < G16p) a.part_out[blockIdx.y * G16p + gx * NC + cq] = (cq == 0) ? tot : 0.0;
     }
 #ifdef CBF_REV_STAMPS
-    if (a.dbg && l == 0 && (w == 0 || w == W - 1)) {
+#ifndef CBF_STAMP_WAVE_PASS
+#define CBF_STAMP_WAVE_PASS (W - 1)     // the second wave whose phase shares are recorded (-DCBF_STAMP_WAVE_PASS=k picks another)
+#endif
+    if (a.dbg && l == 0 && (w == 0 || w == CBF_STAMP_WAVE_PASS)) {
         double* o = a.dbg + (int64_t(blockIdx.y) * a.gtotal + gx) * 64 + (w == 0 ? 0 : 32);
         for (int i = 0; i < 7; ++i) { o[i] = double(st_c[i]); o[7 + i] = double(st_w[i]); }
         for (int i = 0; i < 12; ++i) o[14 + i] = double(st_m[i]);
