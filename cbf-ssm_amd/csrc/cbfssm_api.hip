@@ -641,7 +641,9 @@ __global__ void loglik_moments_kernel(LlArgs a)
 // doubles, parked in an LDS strip, lanes d < dim_x reducing over the particles, the next span's loads in registers meanwhile:
 // 42.5 us against 38.0 us at C3, 327 against 205 us at C5, 37 against 10 us at C2 on a buffer rotation larger than the
 // Infinity Cache.  The 112-byte stride of the form above costs partial lines at L1, not HBM efficiency; what the span form
-// loses is bytes in flight -- 14 reducing lanes per wave behind an LDS round trip.)
+// loses is bytes in flight -- 14 reducing lanes per wave behind an LDS round trip.  Also measured: a persistent grid of 4 .. 16
+// workgroups per CU walking the blocks, ten non-temporal loads in flight per thread: 46.6 .. 50.0 us against 37.8 -- the lanes of
+// a wave touch every 128-byte line in two consecutive iterations, and loads that bypass the cache fetch those lines twice.)
 struct CombineArgs {
     const double* ll; int64_t n_ll;
     const double* kl; int64_t n_kl;
