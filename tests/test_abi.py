@@ -102,3 +102,33 @@ def test_element_counts_come_back_as_64_bit():
     assert n32 == 2 * 1000 * 1600 * 2 * 20 * 256 and n32 > 2 ** 31
     n64 = l.cbfssm_saved_a2_elems(ctypes.byref(prob), ctypes.byref(lay), 1)
     assert n64 == 2 * 1000 * 1600 * 20 * 256
+
+
+def test_variant_entry_points_reject_the_other_variants_problem():
+    """The forward-only variants and CBFSSM share kernels but not entry points: a problem with half = 1 handed to a CBFSSM
+    entry point (or the other way round) is an error with a message, decided on the host before anything is launched --
+    float64 and float32 alike -- and so is an unknown g_mode of the variants' train tail."""
+    import ctypes as C
+    l = lib.load()
+    lay = lib.pack_layout(20, 5, 4)
+    lay_b = lib.pack_layout(20, 5, 2)
+    full = lib.make_problem(2, 3, 6, 4, 1, 2, 20, 3, 1.0, True)
+    half = lib.make_problem(2, 3, 6, 4, 1, 2, 20, 3, 1.0, True, half=True)
+    nul = [None] * 16
+
+    def rc(fn, prob, layout, nargs, *tail):
+        return fn(C.byref(prob), C.byref(layout), *nul[:nargs], *tail)
+    cases = [
+        (l.cbfssm_forward_pass_f64, half, lay, 12), (l.cbfssm_half_forward_pass_f64, full, lay, 12),
+        (l.cbfssm_forward_pass_f32, half, lay, 12), (l.cbfssm_half_forward_pass_f32, full, lay, 12),
+        (l.cbfssm_backward_pass_f32, half, lay_b, 12),
+    ]
+    for fn, prob, layout, nargs in cases:
+        assert rc(fn, prob, layout, nargs) != 0, fn.__name__
+        assert l.cbfssm_last_error().decode(), fn.__name__
+    assert l.cbfssm_forward_pass_bwd_f32(C.byref(half), C.byref(lay), *nul[:10], 1.0, None, None, None) != 0
+    assert b'half' in l.cbfssm_last_error()
+    assert l.cbfssm_half_forward_pass_bwd_f32(C.byref(full), C.byref(lay), *nul[:9], 1.0, None, None, None) != 0
+    assert b'half' in l.cbfssm_last_error()
+    assert l.cbfssm_train_tail_half_f64(C.byref(lay), None, None, 0, None, None, 0, 3, 2, None, None, None, None, None) != 0
+    assert b'g_mode' in l.cbfssm_last_error()
