@@ -25,7 +25,7 @@ SYMBOLS = (
     'cbfssm_train_tail_f64', 'cbfssm_train_tail_g_f64', 'cbfssm_train_tail_half_work_elems', 'cbfssm_train_tail_half_f64', 'cbfssm_gru_recog_param_elems', 'cbfssm_gru_recog_act_elems', 'cbfssm_gru_recog_f64', 'cbfssm_gru_recog_bwd_f64', 'cbfssm_adam_step_f64', 'cbfssm_loglik_partials', 'cbfssm_data_tail_f64', 'cbfssm_stash_contract_work_elems', 'cbfssm_stash_contract_f64',
     'cbfssm_cholesky_f64', 'cbfssm_rbf_k_f64', 'cbfssm_gp_predict_fullq_work_elems', 'cbfssm_gp_predict_fullq_f64',
     'cbfssm_pack_f32_elems', 'cbfssm_gp_pack_f32', 'cbfssm_gp_pack_bf16', 'cbfssm_gp_predict_f32', 'cbfssm_backward_pass_f32', 'cbfssm_forward_pass_f32',
-    'cbfssm_saved_a2_f32_elems', 'cbfssm_half_forward_pass_f32', 'cbfssm_half_forward_pass_bwd_f32', 'cbfssm_rev32_slab_elems', 'cbfssm_forward_pass_bwd_f32', 'cbfssm_backward_pass_bwd_f32',
+    'cbfssm_saved_a2_f32_elems', 'cbfssm_half_forward_pass_f32', 'cbfssm_half_forward_pass_bwd_f32', 'cbfssm_rev32_slab_elems', 'cbfssm_normal_f64', 'cbfssm_philox4x32_10_u32', 'cbfssm_forward_pass_bwd_f32', 'cbfssm_backward_pass_bwd_f32',
 )
 
 
@@ -133,6 +133,8 @@ def load():
     lib.cbfssm_half_forward_pass_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 12
     lib.cbfssm_half_forward_pass_bwd_f32.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout)] + [vp] * 9 + [dbl, vp, vp, vp]
     lib.cbfssm_saved_a2_f32_elems.restype = i64
+    lib.cbfssm_normal_f64.argtypes = [C.c_uint64, C.c_uint64, i64, vp, vp]
+    lib.cbfssm_philox4x32_10_u32.argtypes = [C.c_uint64, C.c_uint64, i64, vp, vp]
     lib.cbfssm_saved_a2_f32_elems.argtypes = [C.POINTER(Problem), C.POINTER(PackLayout), ip]
     lib.cbfssm_rev32_slab_elems.restype = i64
     lib.cbfssm_rev32_slab_elems.argtypes = [C.POINTER(PackLayout)]

@@ -454,12 +454,18 @@ class NoisePipeline:
     One normal per (b, s) and step, as the reference tiles it (cbfssm.py:134,149,209)."""
 
     def __init__(self, device, generator=None, with_backward=True):
+        """The draws come from the library's own generator (cbfssm_normal_f64: Philox4x32-10 + Box-Muller, keyed by the
+        generator's seed, one running element offset per pipeline: a run is reproducible from its seed, whatever the
+        order of buffer sizes); CBFSSM_TORCH_NOISE=1 draws with torch's generator instead."""
         self.device = torch.device(device)
         self.gen = generator
         self.with_backward = with_backward
         self.stream = torch.cuda.Stream(device=self.device)
         self._bufs = {}
         self._ready = {}       # key -> (index of the buffer that holds / is receiving fresh noise, event)
+        self.use_lib = not os.environ.get('CBFSSM_TORCH_NOISE')
+        self.seed = int(generator.initial_seed()) & (2 ** 64 - 1) if generator is not None else int.from_bytes(os.urandom(8), 'little')
+        self.offset = 0        # elements drawn so far
 
     def _numel(self, T, N):
         return (4 * T * N if self.with_backward else 0) + (T - 1) * N
@@ -469,7 +475,13 @@ class NoisePipeline:
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)          # the buffer's previous consumer (issued on `cur`) must be done
         with torch.cuda.stream(self.stream):
-            buf.normal_(generator=self.gen)
+            if self.use_lib:
+                rc = _l.load().cbfssm_normal_f64(self.seed, self.offset, buf.numel(), _ptr(buf),
+                                                 C.c_void_p(self.stream.cuda_stream))
+                _l.check(rc, 'cbfssm_normal_f64')
+                self.offset += buf.numel()
+            else:
+                buf.normal_(generator=self.gen)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._ready[key] = (idx, ev)

@@ -467,6 +467,16 @@ int cbfssm_data_tail_f64(const cbfssm_problem* p, const double* var_y, const dou
 int cbfssm_adam_step_f64(int64_t n, double* pflat, const double* gflat, double* m, double* v, double* t_dev, double lr,
                          double beta1, double beta2, double eps, void* stream);
 
+/* ---- noise.  The reference draws its standard normals inside the graph (tf.random_normal: cbfssm.py:134,149,209;
+ * cbfssmhalf.py:142; prssm.py:126), one per (b, s) chain and step; the passes above take them as arrays (hid_b, eps_b, eps_f).
+ * cbfssm_normal_f64 fills such an array on the device: Philox4x32-10 (counter = element pair index, key = seed) + Box-Muller in
+ * float64.  out[i] is a pure function of (seed, offset + i) -- a caller that advances `offset` by the elements it has drawn
+ * gets one reproducible stream per seed, however the draws are split over calls, streams or devices.
+ * cbfssm_philox4x32_10_u32: the generator's four 32-bit words for the counters first_counter .. first_counter + ncounters - 1
+ * (out: 4 * ncounters words) -- the known-answer vectors of the Philox paper are checked through it. */
+int cbfssm_normal_f64(uint64_t seed, uint64_t offset, int64_t n, double* out, void* stream);
+int cbfssm_philox4x32_10_u32(uint64_t seed, uint64_t first_counter, int64_t ncounters, uint32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

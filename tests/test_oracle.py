@@ -293,3 +293,21 @@ def test_trained_like_fixture_is_this_oracles_output():
     np.testing.assert_allclose(ref['pred_var'], z[tag + 'pred_var'], rtol=1e-8)
     np.testing.assert_allclose(ref['x_final'][:, z['t_sel']], z[tag + 'x_final_sel'], rtol=0,
                                atol=1e-9 * np.abs(ref['x_final']).max())
+
+
+# ---- the noise generator's restatement (oracle/philox.py): pinned by the Philox paper's known-answer vectors
+def test_philox_known_answers():
+    from oracle import philox as ph
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]            # Random123 kat_vectors, philox4x32 10 rounds
+    for ctr, key, want in kat:
+        got = ph.philox4x32_10(np.array(ctr, dtype=np.uint64), np.array(key, dtype=np.uint64))
+        assert [int(v) for v in got] == list(want)
+    # a draw is a function of (seed, offset + i): splitting it changes nothing; the moments are a standard normal's
+    z = ph.normal(2024, 0, 400001)
+    np.testing.assert_array_equal(np.concatenate([ph.normal(2024, 0, 1237), ph.normal(2024, 1237, 400001 - 1237)]), z)
+    assert abs(z.mean()) < 5e-3 and abs(z.std() - 1.0) < 5e-3 and abs((z ** 3).mean()) < 2e-2 and abs((z ** 4).mean() - 3.0) < 5e-2
+    assert np.abs(ph.normal(2025, 0, 1000) - z[:1000]).max() > 1.0                       # another seed, another stream
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 5e-3
