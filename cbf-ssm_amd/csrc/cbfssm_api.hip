@@ -603,8 +603,22 @@ __global__ void loglik_moments_kernel(LlArgs a)
         // differences to the first particle (a shift inside the sample range keeps the cancellation harmless)
         const double x0 = xp[0];
         double s1 = 0.0, s2 = 0.0;
+        // (19 loads in flight per lane -- all of S = 20 -- before the first is consumed: 36.7 us at C3 against 38.7 with eight)
+        constexpr int CH = 19;
+        int s = 1;
+        for (; s + CH <= a.S; s += CH) {
+            double v[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) v[j] = xp[int64_t(s + j) * a.dim_x];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const double dv = v[j] - x0;
+                s1 += dv;
+                s2 += dv * dv;
+            }
+        }
 #pragma unroll 8
-        for (int s = 1; s < a.S; ++s) {
+        for (; s < a.S; ++s) {
             const double dv = xp[int64_t(s) * a.dim_x] - x0;
             s1 += dv;
             s2 += dv * dv;
