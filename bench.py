@@ -141,7 +141,9 @@ def cpu_baseline(w, mode='eval', policy='auto'):
     scale = calls(w.T) / calls(T_s)
     best = min(t_all, t_ref) * scale
     conv = {('T%d' % k): v for k, v in sorted(per_call.items())}
-    return {'value': 1.0 / best, 'unit': 'steps/s', 'cores': host_cores, 'cores_usable': usable, 'cpu_model': _cpu_model(),
+    # `cores`: the threads the quoted value actually ran on (the faster of the two settings); the host's count beside it
+    used = ncores if t_all <= t_ref else 5
+    return {'value': 1.0 / best, 'unit': 'steps/s', 'cores': used, 'host_cores': host_cores, 'cores_usable': usable, 'cpu_model': _cpu_model(),
             'kind': 'port',
             'threads': {'all_cores': {'intra_op': ncores, 'seconds_per_step': t_all * scale},
                         'reference_session_config': {'intra_op': 5, 'inter_op': 10, 'seconds_per_step': t_ref * scale}},
