@@ -1274,7 +1274,18 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         slab[SL::small + 96] = s1;
         slab[SL::small + 97] = s2;
     }
-#ifdef CBF_REV_STAMPS
+#ifdef CBF_STAMP_ALLWAVES
+    // diagnostic: the barrier waits of EVERY row-block wave (who is last at which barrier), 12 slots per wave from 100:
+    // wait[0..6], then the sum of the compute shares (profiles/tools/rev_barrier_waits.py)
+    if (l == 0 && w < 7) {
+        double cs = 0.0;
+        for (int i = 0; i < 7; ++i) {
+            slab[SL::small + 100 + 12 * w + i] = double(st_w[i]);
+            cs += double(st_c[i]);
+        }
+        slab[SL::small + 100 + 12 * w + 7] = cs;
+    }
+#elif defined(CBF_REV_STAMPS)
 #ifndef CBF_STAMP_WAVE
 #define CBF_STAMP_WAVE (W - 1)          // the second wave whose phase shares are recorded (-DCBF_STAMP_WAVE=k picks another)
 #endif
