@@ -61,6 +61,10 @@ def test_variant_bench_lines(model):
     roof = rec['roofline']
     assert roof['bound'] == 'mfma' and roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'])
     assert set(roof['kernel_ms']) == {'forward_pass', 'forward_pass_adjoint'}
+    # ... and in float32 arithmetic against the float32 matrix peak
+    rec = _run('--gpus', '1', '--steps', '3', '--warmup', '1', '--workload', 'C1', '--model', model, '--dtype', 'float32')
+    assert rec['dtype'] == 'f32' and rec['roofline']['peak'] == pytest.approx(157.3) and rec['value'] > 0
+    assert set(rec['roofline']['kernel_ms']) == {'forward_pass', 'forward_pass_adjoint'}
 
 
 def test_two_rank_bench_line_on_one_device():
