@@ -181,16 +181,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
     constexpr int XCB = XW ? REV_XCB : 0;               // column blocks of Kinvbar accumulated by the extra wave
     constexpr int NCB = STASH ? 1 : NBLK - XCB;         // ... and by the wave that owns the row block
     constexpr bool ALL_OK = (NBLK % RB == 0);           // every wave owns RB real row blocks (no predicate around MFMAs)
-#ifdef CBF_GZLATE
-    constexpr bool GZLATE = XW && KSV;
-#else
-    constexpr bool GZLATE = false;
-#endif
-#ifdef CBF_XP2
-    constexpr bool XP2 = XW;
-#else
-    constexpr bool XP2 = false;
-#endif
     typedef Slab<NBLK, JB, STASH> SL;
 
     extern __shared__ double lds[];
@@ -1068,25 +1058,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
         {
 #pragma unroll
             for (int jb = 0; jb < JB; ++jb) xp[jb] = d4{0, 0, 0, 0};
-            if constexpr (XP2 && RB == 1) {
-                // (on the chain: two accumulators per column block and the k-steps interleaved over the blocks -- 2 JB chains of
-                //  two dependent MFMAs instead of JB chains of four)
-                d4 xq2[JB];
-#pragma unroll
-                for (int jb = 0; jb < JB; ++jb) xq2[jb] = d4{0, 0, 0, 0};
-                if (ok[0]) {
-                    const double* ZTp = (ZTLDS ? ZTl : a.rk.ZT) + rbs[0] * JB * 256 + l;
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2)
-#pragma unroll
-                        for (int jb = 0; jb < JB; ++jb) {
-                            xp[jb] = CBF_MFMA(ZTPRE ? ztv[jb][r] : ZTp[(jb * 4 + r) * 64], ebar[0][r], xp[jb]);
-                            xq2[jb] = CBF_MFMA(ZTPRE ? ztv[jb][r + 1] : ZTp[(jb * 4 + r + 1) * 64], ebar[0][r + 1], xq2[jb]);
-                        }
-#pragma unroll
-                    for (int jb = 0; jb < JB; ++jb) xp[jb] = xp[jb] + xq2[jb];
-                }
-            } else {
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 if (ok[i]) {
@@ -1098,7 +1069,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                             xp[jb] = CBF_MFMA(ZTPRE ? ztv[jb][r] : ZTp[(jb * 4 + r) * 64], ebar[i][r], xp[jb]);   // rows j, k = m of this block
                 }
             }
-            }
             if constexpr (!PALIAS && !XW) {
 #pragma unroll
                 for (int jb = 0; jb < JB; ++jb)
@@ -1107,53 +1077,6 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
             }
         }
         CBF_STAMP_MARK(7);
-        if constexpr (!GZLATE) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            if (ok[i]) {
-                double ebT[4];
-                // the K tile is dead after phase E: reuse own rows for Ebar^T -- unless the extra wave is still reading
-                // it: then this wave's (not yet written) slot of the partial tiles is the scratch
-                double* ownk = (XW && !GZLATE) ? (part + w * PSL) : (Kt + 16 * rbs[i] * PD);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ownk[(g + 4 * r) * PD + nl] = ebar[i][r];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int s = 0; s < 4; ++s) ebT[s] = ownk[nl * PD + 4 * s + g];
-#pragma unroll
-                for (int jb = 0; jb < JB; ++jb) {
-                    const int j = 16 * jb + nl;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        double xT = (j < 4 * DK) ? xq[j * PD + 4 * s + g] : 0.0;
-                        if (j == D) xT = 1.0;                                         // ones column: row sums of Ebar
-                        gZ[i][jb] = CBF_MFMA(ebT[s], xT, gZ[i][jb]);                  // Zbar~[m][j] += Ebar[m][n] x~[j][n]
-                    }
-                }
-            }
-        }
-        }
-        CBF_STAMP_MARK(8);
-        if constexpr (XW) {
-            __builtin_amdgcn_wave_barrier();     // the transposes above went through this slot
-#pragma unroll
-            for (int jb = 0; jb < JB; ++jb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
-        }
-        if constexpr (PALIAS) {
-            __syncthreads();                 // every wave is done with its rows of the K tile (Ebar, the transposes)
-#pragma unroll
-            for (int jb = 0; jb < JB; ++jb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
-        }
-        CBF_STAMP_BARRIER(5);
-        if (has_next) load_saved(tn);      // (KSV) a2 / kreg were last read in phase F
-        if constexpr (GZLATE) {
-            // Zbar~ += Ebar x~^T behind barrier 5: it is not on the recurrence's chain, and at the end of phase F it stood between
-            // every wave's partial tile and the barrier phase G waits behind.  (Scratch of the transpose: this wave's rows of
-            // the K tile, which nobody reads after phase E -- the extra wave took its K rows into registers at the top of the step.)
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             if (ok[i]) {
@@ -1178,7 +1101,23 @@ __global__ __launch_bounds__(64 * ((NBLK + RB - 1) / RB + (rev_extra_wave(NBLK, 
                 }
             }
         }
+        CBF_STAMP_MARK(8);
+        if constexpr (XW) {
+            __builtin_amdgcn_wave_barrier();     // the transposes above went through this slot
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
         }
+        if constexpr (PALIAS) {
+            __syncthreads();                 // every wave is done with its rows of the K tile (Ebar, the transposes)
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[w * PSL + (jb * 4 + r) * 64 + l] = xp[jb][r];
+        }
+        CBF_STAMP_BARRIER(5);
+        if (has_next) load_saved(tn);      // (KSV) a2 / kreg were last read in phase F
 
         // ---- G: input adjoint, carried to the next reverse step
         double esum = 0.0;   // colsum of Ebar for this lane's chain = row D of the xbar tile
